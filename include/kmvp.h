@@ -1,0 +1,147 @@
+/* kmvp.h -- C ABI of libkmvp.so, the MI355X (gfx950) kernel matrix-vector product
+ * backend:   a_i = sum_j k(x_i, y_j) b_j   computed on the fly (no N x M matrix).
+ *
+ * The reference (kernel-matrix-benchmarks) has NO native interface: its plugin
+ * boundary is the Python class API of
+ *     kernel_matrix_benchmarks/algorithms/base.py:51-167   (BaseProduct / BaseSolver)
+ * whose only computing implementation is
+ *     kernel_matrix_benchmarks/algorithms/bruteforce.py:61-207.
+ * This header is therefore what a ctypes binding of that class API binds; each
+ * entry point cites the reference method it stands behind.  The Python plugin
+ * (kernel_matrix_benchmarks_amd/algorithms/mi355x.py) is the reference-side
+ * binding; INTEGRATION.md shows the stub a maintainer adds to the reference tree.
+ *
+ * Conventions
+ *  - extern "C", plain C types only; no C++ exception crosses the boundary.
+ *  - every int-returning function returns KMVP_OK (0) or a KMVP_E_* code; the
+ *    message is available from kmvp_last_error(ctx) (ctx may be NULL for errors
+ *    of kmvp_create).
+ *  - host buffers are caller-owned, read during the call only and never
+ *    modified (the runner reuses its numpy arrays across instances,
+ *    runner.py:31-34,70-93); device buffers are ctx-owned.
+ *  - a ctx is bound to ONE GPU and is not thread-safe (the reference's caller
+ *    is single-threaded, main.py:303-308).  Nothing touches the GPU before
+ *    kmvp_create (HIP contexts do not survive the runner's fork).
+ *  - all compute entry points are synchronous: the result is complete in
+ *    device memory when they return (runner.py:138-140 times query() with a
+ *    wall clock).
+ */
+#ifndef KMVP_H
+#define KMVP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMVP_ABI_VERSION 1
+
+enum kmvp_status {
+  KMVP_OK = 0,
+  KMVP_E_INVALID = 1,     /* bad argument or call order                     */
+  KMVP_E_UNSUPPORTED = 2, /* shape / dtype this build has no kernel for     */
+  KMVP_E_DEVICE = 3,      /* HIP runtime error                              */
+  KMVP_E_COMM = 4,        /* RCCL error                                     */
+  KMVP_E_NOMEM = 5,
+  KMVP_E_NOT_CONVERGED = 6
+};
+
+/* working precision of the arithmetic; base.py:9 `precision`, algos.yaml:157-162 */
+enum kmvp_dtype {
+  KMVP_F32 = 0, /* host arrays float32, fp32 VALU kernels (fp64 cross-chunk sums)   */
+  KMVP_F64 = 1, /* host arrays float64, fp64 VALU kernels                           */
+  KMVP_BF16 = 2 /* host arrays float32, bf16 MFMA tiles with fp32 accumulation
+                   (high-D path, D >= 16 only)                                      */
+};
+
+typedef struct kmvp_ctx kmvp_ctx;
+
+int kmvp_abi_version(void);
+/* number of visible GPUs, or a negative kmvp_status; does not create a context */
+int kmvp_device_count(void);
+
+/* BaseAlgorithm.__init__ (base.py:8-29) -- binds the ctx to GPU `device`. */
+kmvp_ctx* kmvp_create(int device, int* status);
+/* BaseAlgorithm.done (base.py:31-33) -- frees every device buffer and the communicator. */
+void kmvp_destroy(kmvp_ctx* ctx);
+const char* kmvp_last_error(const kmvp_ctx* ctx);
+
+/* BaseProduct.prepare_data (base.py:56-80, bruteforce.py:89-111) and
+ * BaseSolver.prepare_data (base.py:124-133).
+ *   y: (M,D) row-major source points of THIS shard, x: (N,D) target points or
+ *   NULL for same_points (then N must equal M_total and, when sharded, x is the
+ *   FULL cloud passed explicitly -- see below).
+ *   dtype: element type of the host arrays / working precision (kmvp_dtype).
+ *   j_offset, M_total: global index of y[0] and global number of sources; pass
+ *   0 and M when the sources are not sharded.  They only matter for the
+ *   inverse-distance kernel, whose zero pattern is defined on the GLOBAL flat
+ *   index (bruteforce.py:13-14).
+ * Uploads and re-lays-out the points (untimed in the harness). */
+int kmvp_set_points(kmvp_ctx* ctx, const void* y, int64_t M, const void* x_or_null, int64_t N,
+                    int D, int dtype, int64_t j_offset, int64_t M_total);
+
+/* BaseProduct.prepare_query (base.py:86-98, bruteforce.py:122-128).
+ *   b: (M,E) row-major signal of this shard in the dtype given to
+ *   kmvp_set_points, or NULL for density estimation (b == 1, E must be 1). */
+int kmvp_set_signal(kmvp_ctx* ctx, const void* b_or_null, int E);
+
+/* BaseProduct.query (base.py:100-106, bruteforce.py:130-153): one entry point per
+ * kernel x normalisation -- there is no kernel-selection branch in device code.
+ *   kmvp_<kernel>       a = K b            (bruteforce.py:150,153)
+ *   kmvp_<kernel>_norm  a = (K b) / (K 1)  (bruteforce.py:134-145)
+ * kernels (bruteforce.py:18-22): gaussian exp(-s); absexp exp(-sqrt(s));
+ * invdist 1/sqrt(s) with the flat-index diagonal zeroed (bruteforce.py:8-15).
+ * With a communicator attached (kmvp_comm_init) the (N,E[+1]) partial sums of
+ * all ranks are all-reduced over RCCL before the normalisation. */
+int kmvp_gaussian(kmvp_ctx* ctx);
+int kmvp_gaussian_norm(kmvp_ctx* ctx);
+int kmvp_absexp(kmvp_ctx* ctx);
+int kmvp_absexp_norm(kmvp_ctx* ctx);
+int kmvp_invdist(kmvp_ctx* ctx);
+int kmvp_invdist_norm(kmvp_ctx* ctx);
+
+/* BaseProduct.get_result (base.py:107-116): (N,E) float64 row-major. */
+int kmvp_get_result(kmvp_ctx* ctx, double* out, int64_t out_len);
+
+/* BaseSolver.prepare_query + query (base.py:140-156, bruteforce.py:201-207): solves
+ * K b = a on the point cloud given to kmvp_set_points (x_or_null == NULL) by
+ * conjugate gradients with the on-the-fly product as operator.  The reference
+ * uses a dense lstsq; parity is judged on the residual.
+ *   a: (M,E) in the ctx dtype.  rtol: target ||K b - a|| / ||a|| (per column).
+ *   out_b (M,E) float64 receives the iterate; *iters / *resid the iteration
+ *   count and the worst final relative residual.  Returns KMVP_E_NOT_CONVERGED
+ *   (with out_b still written) when maxit is reached. */
+int kmvp_gaussian_cg_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, int maxit,
+                           double* out_b, int* iters, double* resid);
+int kmvp_absexp_cg_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, int maxit,
+                         double* out_b, int* iters, double* resid);
+
+/* Source sharding over the GPUs of one node, one process per GPU:
+ * rank 0 calls kmvp_comm_get_unique_id and hands the 128 bytes to every rank
+ * out of band; every rank then calls kmvp_comm_init.  world == 1 is allowed. */
+#define KMVP_UNIQUE_ID_BYTES 128
+int kmvp_comm_get_unique_id(void* id128);
+int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
+
+/* BaseAlgorithm.set_query_arguments (base.py:40-42): tuning knobs, all optional.
+ *   "feed"             0 = scalar-cache source stream (default), 1 = LDS-staged tiles
+ *   "targets_per_lane" 1, 2 or 4
+ *   "segments"         number of source segments a launch is split into (0 = auto)
+ *   "chunk"            sources summed in fp32 before folding into the fp64 sum */
+int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);
+
+/* BaseAlgorithm.get_memory_usage / get_additional (base.py:35-46): bytes of device
+ * memory the ctx holds, and HIP-event timings of the last compute call:
+ *   kmvp_last_kernel_ms  the dominant (pair-loop) kernel alone
+ *   kmvp_last_total_ms   every launch of the call incl. reduction + all-reduce */
+int64_t kmvp_device_bytes(const kmvp_ctx* ctx);
+double kmvp_last_kernel_ms(const kmvp_ctx* ctx);
+double kmvp_last_total_ms(const kmvp_ctx* ctx);
+/* name of the pair-loop kernel the last compute call launched (for rocprof matching) */
+const char* kmvp_last_kernel_name(const kmvp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMVP_H */

@@ -1,0 +1,43 @@
+// Host-side declarations shared by the translation units of libkmvp.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmvp_lowd.hpp"
+
+namespace kmvp {
+
+// Tuning of a specialised low-D launch (host-side choice, compile-time in the kernel).
+struct LowdTuning {
+  int targets_per_lane;  // T
+  int feed;              // 0 scalar-cache stream, 1 LDS tiles
+};
+
+// Largest shapes the specialised kernels are instantiated for; anything else goes
+// to lowd_generic_kernel (or to the MFMA path for bf16).
+constexpr int LOWD_MAX_D = 8;
+constexpr int LOWD_MAX_E = 4;
+
+// default T for a point dimension (register budget: T*(D+NE) VGPRs of state)
+inline int default_targets_per_lane(int D) { return D <= 4 ? 4 : 2; }
+
+// Returns hipErrorInvalidValue when (D, E, sig, tuning) has no instantiation.
+// One function per kernel x precision: each lives in its own translation unit
+// (kmvp_lowd_inst.hip compiled with -DKMVP_KERNEL / -DKMVP_REAL) and contains no
+// kernel-selection branch in device code.
+#define KMVP_DECLARE_LOWD(NAME, REAL)                                                           \
+  hipError_t NAME(int D, int E, int sig, LowdTuning tune, const LowdArgs<REAL>& args, dim3 grid, \
+                  hipStream_t stream, const char** kernel_name);                                \
+  hipError_t NAME##_generic(int sig, const REAL* x, const REAL* y, const REAL* b, double* part,  \
+                            int64_t n, int64_t n_pad, int64_t m, int D, int E, int NE,           \
+                            int segments, int64_t seg_len, int64_t j_offset, int64_t m_total,    \
+                            hipStream_t stream, const char** kernel_name);
+
+KMVP_DECLARE_LOWD(launch_lowd_gaussian_f32, float)
+KMVP_DECLARE_LOWD(launch_lowd_absexp_f32, float)
+KMVP_DECLARE_LOWD(launch_lowd_invdist_f32, float)
+KMVP_DECLARE_LOWD(launch_lowd_gaussian_f64, double)
+KMVP_DECLARE_LOWD(launch_lowd_absexp_f64, double)
+KMVP_DECLARE_LOWD(launch_lowd_invdist_f64, double)
+
+}  // namespace kmvp

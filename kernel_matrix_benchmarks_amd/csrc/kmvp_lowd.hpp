@@ -1,0 +1,433 @@
+// Low-dimensional pair-loop kernels for gfx950 (CDNA4): a_i = sum_j k(x_i, y_j) b_j.
+//
+// Arithmetic restated from the reference's dense bruteforce plugin
+// (kernel_matrix_benchmarks/algorithms/bruteforce.py): squared distances in the
+// difference form of :53-54, kernel functions of :18-22 / :8-15, the four
+// query() branches of :130-153.  Nothing here is a translation: the reference
+// materialises the (N,M) matrix and calls BLAS, this file never forms it.
+//
+// Mapping to the hardware
+//  * lanes = targets.  One 64-lane wavefront owns one target tile of 64*T points;
+//    each lane keeps T targets (coordinates + partial sums) in VGPRs for the
+//    whole launch, so a source record is reused 64*T times per wave.
+//  * sources are wave-uniform.  They are stored as packed records
+//    [y_0..y_{D-1}, b_0..b_{E-1}, pad] (R dwords, written by pack_sources with the
+//    kernel's constant folded into the coordinates) and reach the VALU either
+//      FEED 0: through the scalar data cache into SGPRs (s_load_dwordxN) -- a
+//              source costs no VGPR, no LDS cycle and no vector-memory issue; or
+//      FEED 1: through an LDS tile the workgroup fills with coalesced 16-byte
+//              global loads, read back as broadcast ds_read_b128.
+//  * the launch is a 2-D decomposition: target tile-blocks x source segments.
+//    blockIdx is remapped so that all blocks of one source segment share
+//    blockIdx % 8, i.e. one XCD and one L2 (placement is a speed matter only).
+//  * sums: fp32 inside a chunk of `chunk` sources, folded into an fp64 per-target
+//    running sum between chunks; each (segment, target) partial is written once
+//    as fp64 and the segments are added in index order by reduce_segments, so
+//    results are bitwise reproducible run to run (no atomics).
+//  * roofline: the loop is bound by VALU issue, not by HBM: per pair
+//    3D-1 full-rate ops for the squared distance, one (gaussian, 1/r) or two
+//    (exp(-r)) quarter-rate transcendentals, E (+1 normalised) FMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmvp {
+
+enum : int { K_GAUSSIAN = 0, K_ABSEXP = 1, K_INVDIST = 2 };
+
+// signal mode of a launch
+enum : int {
+  SIG_PRODUCT = 0,  // a = K b                 (bruteforce.py:153)
+  SIG_NORM = 1,     // numerator K b and denominator K 1 in one sweep (bruteforce.py:142-145)
+  SIG_DENSITY = 2   // a = K 1, no signal read (bruteforce.py:150)
+};
+
+template <typename real>
+struct LowdArgs {
+  const real* xs;    // targets, SoA: xs[d * n_pad + i], kernel constant folded in
+  const real* rec;   // source records, [m_pad][R]
+  double* part;      // partial sums [segments][NE][n_pad]
+  int64_t n;         // targets
+  int64_t n_pad;     // targets rounded up to the tile-block size
+  int64_t m_pad;     // sources rounded up to the batch size (pad records contribute 0)
+  int64_t seg_len;   // sources per segment (multiple of the batch size)
+  int segments;      // source segments (grid = tile_blocks * segments)
+  int tile_blocks;   // target tile-blocks
+  int chunk;         // sources per fp32 chunk
+  int64_t j_offset;  // global index of source 0 (sharding)
+  int64_t m_total;   // global number of sources (inverse-distance zero pattern)
+};
+
+__device__ __forceinline__ float kexp2(float v) { return __builtin_amdgcn_exp2f(v); }
+
+// kernel value from the squared distance of the (pre-scaled) coordinates
+template <int KERNEL>
+__device__ __forceinline__ float kval(float s) {
+  if constexpr (KERNEL == K_GAUSSIAN) {
+    return kexp2(-s);  // coordinates carry sqrt(log2 e): exp(-|x-y|^2) = 2^(-s)
+  } else if constexpr (KERNEL == K_ABSEXP) {
+    return kexp2(-__builtin_amdgcn_sqrtf(s));  // coordinates carry log2 e
+  } else {
+    return __builtin_amdgcn_rsqf(s);  // 1/sqrt(0) = inf, as the reference's 1/np.sqrt
+  }
+}
+template <int KERNEL>
+__device__ __forceinline__ double kval(double s) {
+  if constexpr (KERNEL == K_GAUSSIAN) {
+    return exp(-s);
+  } else if constexpr (KERNEL == K_ABSEXP) {
+    return exp(-sqrt(s));
+  } else {
+    return 1.0 / sqrt(s);
+  }
+}
+
+// coordinate pre-scale that turns exp() into the hardware's exp2()
+template <int KERNEL, typename real>
+__host__ __device__ inline real coord_scale() {
+  if constexpr (sizeof(real) == 8) return (real)1;
+  if constexpr (KERNEL == K_GAUSSIAN) return (real)1.2011224087864498;  // sqrt(log2 e)
+  if constexpr (KERNEL == K_ABSEXP) return (real)1.4426950408889634;    // log2 e
+  return (real)1;
+}
+
+// blockIdx -> (tile-block, segment).  With segments % 8 == 0 every block of a
+// segment has the same blockIdx % 8 (round-robin XCD dispatch => same L2).
+__device__ __forceinline__ void block_to_work(int bid, int segments, int& tb, int& seg) {
+  if ((segments & 7) == 0) {
+    const int s8 = segments >> 3;
+    const int q = bid >> 3;
+    seg = (bid & 7) + 8 * (q % s8);
+    tb = q / s8;
+  } else {
+    seg = bid % segments;
+    tb = bid / segments;
+  }
+}
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+constexpr int LDS_TILE = 256;  // source records per LDS tile (FEED 1)
+
+template <int D, int E, int SIG>
+struct RecLayout {
+  static constexpr int EB = (SIG == SIG_DENSITY) ? 0 : E;  // signal dwords in a record
+  static constexpr int R = ((D + EB + 3) / 4) * 4;         // record length in elements
+  static constexpr int NE = (SIG == SIG_DENSITY) ? 1 : (SIG == SIG_NORM ? E + 1 : E);
+};
+
+// One (target, source) interaction for all T targets of the lane.
+template <int KERNEL, int D, int E, int SIG, int T, bool CHECK_DIAG, typename real>
+__device__ __forceinline__ void interact(const real (&x)[T][D], real (&acc)[T][RecLayout<D, E, SIG>::NE],
+                                         const real* __restrict__ r, const int64_t (&jz)[T],
+                                         int64_t j_local) {
+  using L = RecLayout<D, E, SIG>;
+  real y[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) y[d] = r[d];
+  real b[L::EB > 0 ? L::EB : 1];
+#pragma unroll
+  for (int e = 0; e < L::EB; ++e) b[e] = r[D + e];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    real df = x[t][0] - y[0];
+    real s = df * df;
+#pragma unroll
+    for (int d = 1; d < D; ++d) {
+      df = x[t][d] - y[d];
+      s = fma(df, df, s);
+    }
+    real k = kval<KERNEL>(s);
+    if constexpr (CHECK_DIAG) k = (j_local == jz[t]) ? (real)0 : k;
+    if constexpr (SIG == SIG_DENSITY) {
+      acc[t][0] += k;
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[t][e] = fma(k, b[e], acc[t][e]);
+      if constexpr (SIG == SIG_NORM) acc[t][E] += k;
+    }
+  }
+}
+
+template <int KERNEL, int D, int E, int SIG, int T, int FEED, typename real>
+__global__ void __launch_bounds__(BLOCK_THREADS) lowd_kernel(const LowdArgs<real> a) {
+  using L = RecLayout<D, E, SIG>;
+  constexpr int R = L::R;
+  constexpr int NE = L::NE;
+  constexpr int U = 4;  // sources per batch; segments start on batch boundaries
+  constexpr bool F32 = sizeof(real) == 4;
+
+  int tb, seg;
+  block_to_work((int)blockIdx.x, a.segments, tb, seg);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  // first target of this wave's tile
+  const int64_t i0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * (64 * T);
+
+  real x[T][D];
+  int64_t jz[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int64_t i = i0 + t * 64 + lane;  // < n_pad by construction; pad targets are 0
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[t][d] = a.xs[(int64_t)d * a.n_pad + i];
+    if constexpr (KERNEL == K_INVDIST) {
+      // bruteforce.py:13-14: flat index i*M+j is zeroed when it is a multiple of M+1,
+      // i.e. column (i mod (M+1)) if that is < M.  Local column = global - j_offset.
+      const int64_t g = i % (a.m_total + 1);
+      jz[t] = (g < a.m_total) ? g - a.j_offset : (int64_t)-1;
+    } else {
+      jz[t] = -1;
+    }
+  }
+  // wave-uniform bounds of the zero columns of this tile (conservative when the
+  // mod wraps inside the tile: then every batch is checked)
+  int64_t jz_lo = 0, jz_hi = -1;
+  if constexpr (KERNEL == K_INVDIST) {
+    const int64_t g_lo = i0 % (a.m_total + 1);
+    const int64_t g_hi = g_lo + (64 * T - 1);
+    if (g_hi <= a.m_total) {
+      jz_lo = g_lo - a.j_offset;
+      jz_hi = g_hi - a.j_offset;
+    } else {
+      jz_lo = INT64_MIN / 2;
+      jz_hi = INT64_MAX / 2;
+    }
+  }
+
+  const int64_t seg_begin = (int64_t)seg * a.seg_len;
+  int64_t seg_end = seg_begin + a.seg_len;
+  if (seg_end > a.m_pad) seg_end = a.m_pad;
+
+  double accd[T][NE];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) accd[t][e] = 0.0;
+
+  real acc[T][NE];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[t][e] = 0;
+
+  auto fold = [&]() {
+    if constexpr (F32) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          accd[t][e] += (double)acc[t][e];
+          acc[t][e] = 0;
+        }
+    }
+  };
+
+  if constexpr (FEED == 0) {
+    // ---- scalar-cache stream: the record address depends on blockIdx and the loop
+    // counter only, so the loads are s_load_dwordxN into SGPRs.  The next batch is
+    // requested before the current one is consumed (the record array carries one
+    // spare batch at its end, so the last prefetch stays in bounds).
+    const real* __restrict__ segp = a.rec + seg_begin * R;
+    const int seg_n = (int)(seg_end - seg_begin);
+    const int jz_lo32 = (int)max((int64_t)-1, min(jz_lo - seg_begin, (int64_t)INT32_MAX));
+    const int jz_hi32 = (int)max((int64_t)-2, min(jz_hi - seg_begin, (int64_t)INT32_MAX));
+    int64_t jzl[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) jzl[t] = jz[t] - seg_begin;
+    // two SGPR batches in ping-pong: batch B is requested before batch A is consumed
+    // and vice versa (segments hold a whole number of 2*U sources).
+    auto run_batch = [&](const real (&rb)[U * R], int j) {
+      bool check = false;
+      if constexpr (KERNEL == K_INVDIST) check = (j + U - 1 >= jz_lo32) && (j <= jz_hi32);
+      if (check) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          interact<KERNEL, D, E, SIG, T, true, real>(x, acc, rb + u * R, jzl, (int64_t)(j + u));
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          interact<KERNEL, D, E, SIG, T, false, real>(x, acc, rb + u * R, jzl, (int64_t)(j + u));
+      }
+    };
+    real ra[U * R], rb[U * R];
+#pragma unroll
+    for (int q = 0; q < U * R; ++q) ra[q] = segp[q];
+    for (int c0 = 0; c0 < seg_n; c0 += a.chunk) {
+      const int c1 = min(c0 + a.chunk, seg_n);
+      for (int j = c0; j < c1; j += 2 * U) {
+        const real* __restrict__ pb = segp + (int64_t)(j + U) * R;
+#pragma unroll
+        for (int q = 0; q < U * R; ++q) rb[q] = pb[q];
+        run_batch(ra, j);
+        const real* __restrict__ pa = segp + (int64_t)(j + 2 * U) * R;
+#pragma unroll
+        for (int q = 0; q < U * R; ++q) ra[q] = pa[q];
+        run_batch(rb, j + U);
+      }
+      fold();
+    }
+  } else {
+    // ---- LDS-staged tiles: coalesced 16-byte loads of LDS_TILE records per block,
+    // double buffered (one barrier per tile), broadcast reads in the pair loop.
+    static_assert((LDS_TILE * R * sizeof(real)) % (16 * BLOCK_THREADS) == 0 ||
+                      (LDS_TILE * R * sizeof(real)) < (16 * BLOCK_THREADS),
+                  "tile must be a whole number of 16-byte pieces per thread");
+    constexpr int TILE_BYTES = LDS_TILE * R * (int)sizeof(real);
+    constexpr int PIECES = (TILE_BYTES + 16 * BLOCK_THREADS - 1) / (16 * BLOCK_THREADS);
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2][TILE_BYTES];
+    const int64_t n_tiles = (seg_end - seg_begin + LDS_TILE - 1) / LDS_TILE;
+    const unsigned char* gbase = reinterpret_cast<const unsigned char*>(a.rec + seg_begin * R);
+    const int64_t seg_bytes = (seg_end - seg_begin) * R * (int64_t)sizeof(real);
+    uint4 stage[PIECES];
+    auto gload = [&](int64_t tile) {
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) {
+        const int64_t off = tile * TILE_BYTES + ((int64_t)p * BLOCK_THREADS + threadIdx.x) * 16;
+        stage[p] = (off < seg_bytes && (p * BLOCK_THREADS + (int)threadIdx.x) * 16 < TILE_BYTES)
+                       ? *reinterpret_cast<const uint4*>(gbase + off)
+                       : make_uint4(0, 0, 0, 0);
+      }
+    };
+    gload(0);
+    int since_fold = 0;
+    for (int64_t tile = 0; tile < n_tiles; ++tile) {
+      const int buf = (int)(tile & 1);
+#pragma unroll
+      for (int p = 0; p < PIECES; ++p) {
+        const int o = (p * BLOCK_THREADS + (int)threadIdx.x) * 16;
+        if (o < TILE_BYTES) *reinterpret_cast<uint4*>(&lds_raw[buf][o]) = stage[p];
+      }
+      __syncthreads();
+      if (tile + 1 < n_tiles) gload(tile + 1);
+      const int64_t jt = seg_begin + tile * LDS_TILE;
+      int cnt = LDS_TILE;
+      if (jt + cnt > seg_end) cnt = (int)(seg_end - jt);
+      const real* lrec = reinterpret_cast<const real*>(&lds_raw[buf][0]);
+      for (int jj = 0; jj < cnt; jj += U) {
+        const int64_t j = jt + jj;
+        bool check = false;
+        if constexpr (KERNEL == K_INVDIST) check = (j + U - 1 >= jz_lo) && (j <= jz_hi);
+        if (check) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            interact<KERNEL, D, E, SIG, T, true, real>(x, acc, lrec + (jj + u) * R, jz, j + u);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            interact<KERNEL, D, E, SIG, T, false, real>(x, acc, lrec + (jj + u) * R, jz, j + u);
+        }
+      }
+      since_fold += LDS_TILE;
+      if (since_fold >= a.chunk) {
+        fold();
+        since_fold = 0;
+      }
+    }
+    fold();
+  }
+
+  // ---- one fp64 partial per (segment, output column, target); coalesced over targets
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int64_t i = i0 + t * 64 + lane;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      double v;
+      if constexpr (F32) v = accd[t][e];
+      else v = (double)acc[t][e];
+      a.part[((int64_t)seg * NE + e) * a.n_pad + i] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// generic fallback: any D, any E (runtime), one target per lane, coordinates of the
+// lane's target in LDS, signal columns in blocks of 8 (the kernel value is
+// recomputed per block).  Correct for every shape; only the specialised kernels
+// above are tuned.
+template <int KERNEL, int SIG, typename real>
+__global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
+    const real* __restrict__ x,  // (N,D) row-major, scaled
+    const real* __restrict__ y,  // (M,D) row-major, scaled
+    const real* __restrict__ b,  // (M,E) row-major or null
+    double* __restrict__ part,   // [segments][NE][n_pad]
+    int64_t n, int64_t n_pad, int64_t m, int D, int E, int NE, int segments, int64_t seg_len,
+    int64_t j_offset, int64_t m_total) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  real* xl = reinterpret_cast<real*>(dyn_lds);  // [D][BLOCK_THREADS]
+  const int seg = (int)(blockIdx.x % segments);
+  const int64_t tb = blockIdx.x / segments;
+  const int64_t i = tb * BLOCK_THREADS + threadIdx.x;
+  const int64_t ic = i < n ? i : n - 1;
+  for (int d = 0; d < D; ++d) xl[d * BLOCK_THREADS + threadIdx.x] = x[ic * D + d];
+  int64_t jz = -1;
+  if constexpr (KERNEL == K_INVDIST) {
+    const int64_t g = ic % (m_total + 1);
+    jz = (g < m_total) ? g - j_offset : (int64_t)-1;
+  }
+  const int64_t j0 = (int64_t)seg * seg_len;
+  int64_t j1 = j0 + seg_len;
+  if (j1 > m) j1 = m;
+  const int EB = (SIG == SIG_DENSITY) ? 0 : E;
+  for (int e0 = 0; e0 < NE; e0 += 8) {
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+    for (int64_t j = j0; j < j1; ++j) {
+      real s = 0;
+      for (int d = 0; d < D; ++d) {
+        const real df = xl[d * BLOCK_THREADS + threadIdx.x] - y[j * D + d];
+        s = fma(df, df, s);
+      }
+      real k = kval<KERNEL>(s);
+      if constexpr (KERNEL == K_INVDIST) k = (j == jz) ? (real)0 : k;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = e0 + q;
+        if (e < EB) acc[q] += (double)(k * b[j * E + e]);
+        else if (e < NE) acc[q] += (double)k;  // denominator column / density
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = e0 + q;
+      if (e < NE && i < n_pad) part[((int64_t)seg * NE + e) * n_pad + i] = acc[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// layout + epilogue kernels (HBM-bound, tiny next to the pair loop)
+
+// targets (N,D) row-major -> SoA xs[d*n_pad + i] * scale ; pad targets are 0
+template <typename real>
+__global__ void pack_targets_kernel(const real* __restrict__ x, real* __restrict__ xs, int64_t n,
+                                    int64_t n_pad, int D, real scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  for (int d = 0; d < D; ++d) xs[(int64_t)d * n_pad + i] = i < n ? x[i * D + d] * scale : (real)0;
+}
+
+// sources (M,D) + signal (M,E) -> records [m_pad][R]; pad records have y = +inf and
+// b = 0 so that every kernel evaluates to exactly 0 for them.
+template <typename real>
+__global__ void pack_sources_kernel(const real* __restrict__ y, const real* __restrict__ b,
+                                    real* __restrict__ rec, int64_t m, int64_t m_pad, int D, int EB,
+                                    int R, real scale) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m_pad) return;
+  real* r = rec + j * R;
+  for (int d = 0; d < D; ++d) r[d] = j < m ? y[j * D + d] * scale : (real)INFINITY;
+  for (int e = 0; e < EB; ++e) r[D + e] = j < m ? b[j * EB + e] : (real)0;
+  for (int q = D + EB; q < R; ++q) r[q] = (real)0;
+}
+
+template <typename real>
+__global__ void scale_kernel(const real* __restrict__ in, real* __restrict__ out, int64_t count,
+                             real scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = in[i] * scale;
+}
+
+}  // namespace kmvp

@@ -1,0 +1,125 @@
+// Instantiations of the low-D pair-loop kernels for ONE kernel function and ONE
+// precision.  Compiled six times (see Makefile):
+//   -DKMVP_KERNEL={0,1,2}  -DKMVP_REAL={float,double}  -DKMVP_FN=launch_lowd_<k>_<p>
+// so that each kernel function is its own set of device kernels (no runtime
+// kernel dispatch inside device code) and the six units build in parallel.
+#include "kmvp_internal.hpp"
+
+#ifndef KMVP_KERNEL
+#error "KMVP_KERNEL, KMVP_REAL and KMVP_FN must be defined"
+#endif
+
+namespace kmvp {
+
+using real = KMVP_REAL;
+constexpr int KERNEL = KMVP_KERNEL;
+
+#define KMVP_STR2(x) #x
+#define KMVP_STR(x) KMVP_STR2(x)
+
+template <int D, int E, int SIG, int T, int FEED>
+static hipError_t launch_one(const LowdArgs<real>& args, dim3 grid, hipStream_t stream,
+                             const char** kernel_name) {
+  hipLaunchKernelGGL((lowd_kernel<KERNEL, D, E, SIG, T, FEED, real>), grid, dim3(BLOCK_THREADS), 0,
+                     stream, args);
+  if (kernel_name) *kernel_name = "lowd_kernel";
+  return hipGetLastError();
+}
+
+// T / FEED variants: every shape gets its default T with the scalar-cache feed; the
+// headline shape (D=3, E=1) additionally gets the whole tuning grid so that the
+// choice is made from measurements, not guesses.
+template <int D, int E, int SIG>
+static hipError_t launch_te(LowdTuning tune, const LowdArgs<real>& args, dim3 grid,
+                            hipStream_t stream, const char** kernel_name) {
+  constexpr int TD = (D <= 4) ? 4 : 2;
+  if (tune.feed == 0 && tune.targets_per_lane == TD)
+    return launch_one<D, E, SIG, TD, 0>(args, grid, stream, kernel_name);
+  if constexpr (D == 3 && E == 1) {
+    if (tune.feed == 0 && tune.targets_per_lane == 1) return launch_one<D, E, SIG, 1, 0>(args, grid, stream, kernel_name);
+    if (tune.feed == 0 && tune.targets_per_lane == 2) return launch_one<D, E, SIG, 2, 0>(args, grid, stream, kernel_name);
+    if (tune.feed == 0 && tune.targets_per_lane == 8) return launch_one<D, E, SIG, 8, 0>(args, grid, stream, kernel_name);
+    if (tune.feed == 1 && tune.targets_per_lane == 1) return launch_one<D, E, SIG, 1, 1>(args, grid, stream, kernel_name);
+    if (tune.feed == 1 && tune.targets_per_lane == 2) return launch_one<D, E, SIG, 2, 1>(args, grid, stream, kernel_name);
+    if (tune.feed == 1 && tune.targets_per_lane == 4) return launch_one<D, E, SIG, 4, 1>(args, grid, stream, kernel_name);
+    if (tune.feed == 1 && tune.targets_per_lane == 8) return launch_one<D, E, SIG, 8, 1>(args, grid, stream, kernel_name);
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int D, int SIG>
+static hipError_t launch_e(int E, LowdTuning tune, const LowdArgs<real>& args, dim3 grid,
+                           hipStream_t stream, const char** kernel_name) {
+  if constexpr (SIG == SIG_DENSITY) {
+    return launch_te<D, 1, SIG>(tune, args, grid, stream, kernel_name);
+  } else {
+    switch (E) {
+      case 1: return launch_te<D, 1, SIG>(tune, args, grid, stream, kernel_name);
+      case 2: return launch_te<D, 2, SIG>(tune, args, grid, stream, kernel_name);
+      case 3: return launch_te<D, 3, SIG>(tune, args, grid, stream, kernel_name);
+      case 4: return launch_te<D, 4, SIG>(tune, args, grid, stream, kernel_name);
+      default: return hipErrorInvalidValue;
+    }
+  }
+}
+
+template <int SIG>
+static hipError_t launch_d(int D, int E, LowdTuning tune, const LowdArgs<real>& args, dim3 grid,
+                           hipStream_t stream, const char** kernel_name) {
+  switch (D) {
+    case 1: return launch_e<1, SIG>(E, tune, args, grid, stream, kernel_name);
+    case 2: return launch_e<2, SIG>(E, tune, args, grid, stream, kernel_name);
+    case 3: return launch_e<3, SIG>(E, tune, args, grid, stream, kernel_name);
+    case 4: return launch_e<4, SIG>(E, tune, args, grid, stream, kernel_name);
+    case 5: return launch_e<5, SIG>(E, tune, args, grid, stream, kernel_name);
+    case 6: return launch_e<6, SIG>(E, tune, args, grid, stream, kernel_name);
+    case 7: return launch_e<7, SIG>(E, tune, args, grid, stream, kernel_name);
+    case 8: return launch_e<8, SIG>(E, tune, args, grid, stream, kernel_name);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t KMVP_FN(int D, int E, int sig, LowdTuning tune, const LowdArgs<real>& args, dim3 grid,
+                   hipStream_t stream, const char** kernel_name) {
+  switch (sig) {
+    case SIG_PRODUCT: return launch_d<SIG_PRODUCT>(D, E, tune, args, grid, stream, kernel_name);
+    case SIG_NORM: return launch_d<SIG_NORM>(D, E, tune, args, grid, stream, kernel_name);
+    case SIG_DENSITY: return launch_d<SIG_DENSITY>(D, E, tune, args, grid, stream, kernel_name);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+#define KMVP_CAT2(a, b) a##b
+#define KMVP_CAT(a, b) KMVP_CAT2(a, b)
+
+hipError_t KMVP_CAT(KMVP_FN, _generic)(int sig, const real* x, const real* y, const real* b,
+                                       double* part, int64_t n, int64_t n_pad, int64_t m, int D,
+                                       int E, int NE, int segments, int64_t seg_len,
+                                       int64_t j_offset, int64_t m_total, hipStream_t stream,
+                                       const char** kernel_name) {
+  const dim3 grid((unsigned)((n_pad / BLOCK_THREADS) * segments));
+  const size_t lds = (size_t)D * BLOCK_THREADS * sizeof(real);
+  if (kernel_name) *kernel_name = "lowd_generic_kernel";
+  switch (sig) {
+    case SIG_PRODUCT:
+      hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_PRODUCT, real>), grid, dim3(BLOCK_THREADS),
+                         lds, stream, x, y, b, part, n, n_pad, m, D, E, NE, segments, seg_len,
+                         j_offset, m_total);
+      break;
+    case SIG_NORM:
+      hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_NORM, real>), grid, dim3(BLOCK_THREADS),
+                         lds, stream, x, y, b, part, n, n_pad, m, D, E, NE, segments, seg_len,
+                         j_offset, m_total);
+      break;
+    case SIG_DENSITY:
+      hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_DENSITY, real>), grid,
+                         dim3(BLOCK_THREADS), lds, stream, x, y, b, part, n, n_pad, m, D, E, NE,
+                         segments, seg_len, j_offset, m_total);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace kmvp
