@@ -125,8 +125,8 @@ int kmvp_comm_get_unique_id(void* id128);
 int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
 
 /* BaseAlgorithm.set_query_arguments (base.py:40-42): tuning knobs, all optional.
- *   "feed"             0 = scalar-cache source stream (default), 1 = LDS-staged tiles
- *   "targets_per_lane" 1, 2 or 4
+ *   "feed"             -1 = auto (default), 0 = scalar-cache source stream, 1 = LDS-staged tiles
+ *   "targets_per_lane" 0 = auto (default), 1, 2, 4 or 8
  *   "segments"         number of source segments a launch is split into (0 = auto)
  *   "chunk"            sources summed in fp32 before folding into the fp64 sum */
 int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmvp.so")
+LIB_PATH = os.environ.get("KMVP_LIB", os.path.join(_HERE, "libkmvp.so"))
 
 KMVP_F32, KMVP_F64, KMVP_BF16 = 0, 1, 2
 STATUS = {

@@ -1,0 +1,205 @@
+"""MI355X plugins: the on-the-fly kernel product and the CG solver built on it.
+
+Drop-in counterparts of the reference's ``BruteForceProductBLAS``
+(bruteforce.py:61-153) and ``BruteForceSolverLAPACK`` (bruteforce.py:156-207):
+same constructor keywords, same method order, same result type.  All arithmetic
+happens in ``libkmvp.so`` (hand-written HIP kernels for gfx950) behind the C ABI
+of ``include/kmvp.h``.  There is no CPU path: without the library or a GPU the
+calls raise.
+
+Differences a user should know about
+ * ``fit()`` has nothing to pre-compute (no N x M matrix exists); compare on
+   build_time + query_time, which is the harness' default axis (plot.py:128).
+ * The HIP context is created in ``prepare_data`` -- never at import or
+   construction -- because the harness imports plugins in its parent process
+   before forking the worker (main.py:262-308).
+ * The solver is conjugate gradients on the product operator with a residual
+   stopping rule; the dense ``lstsq`` of the reference cannot be matched
+   vector-for-vector on these numerically singular matrices, so it
+   reports (and is tested on) the relative residual.
+"""
+import numpy as np
+
+from kernel_matrix_benchmarks_amd import _lib
+from kernel_matrix_benchmarks_amd.algorithms.base import BaseProduct, BaseSolver
+from kernel_matrix_benchmarks_amd import sharding
+
+SUPPORTED_KERNELS = ("gaussian", "absolute-exponential", "inverse-distance")
+
+
+def _precision_name(precision):
+    if isinstance(precision, str):
+        return precision
+    return np.dtype(precision).name
+
+
+class MI355XProduct(BaseProduct):
+    """a_i = sum_j k(x_i, y_j) b_j on one MI355X, or on several with the sources
+    sharded over ranks (``comm`` = a ``sharding.Communicator``)."""
+
+    def __init__(self, *, kernel, dimension, normalize_rows=False, precision=np.float32,
+                 device=0, comm=None, targets_per_lane=0, feed=None, segments=0, chunk=0):
+        super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows,
+                         precision=precision)
+        if kernel not in SUPPORTED_KERNELS:
+            # same failure mode as bruteforce.py:82-85
+            raise NotImplementedError(f"MI355XProduct doesn't support kernel {kernel}.")
+        self._dtype_code, self._host_dtype = _lib.dtype_code(precision)  # NotImplementedError if unknown
+        self.device = device
+        self.comm = comm
+        self._options = dict(targets_per_lane=targets_per_lane, feed=feed, segments=segments,
+                             chunk=chunk)
+        self._ctx = None
+        self.res = None
+        self.name = f"MI355XProduct({_precision_name(precision)})"
+
+    # -- untimed -------------------------------------------------------------------
+    def prepare_data(self, *, source_points, target_points, same_points=False,
+                     density_estimation=False):
+        # h5py hands numpy.bool_ attributes over (runner.py:41-43)
+        self.same_points = bool(same_points)
+        self.density_estimation = bool(density_estimation)
+        y = np.ascontiguousarray(source_points, dtype=self._host_dtype)
+        self.M, self.D = y.shape
+        if self.same_points:
+            x = None
+            self.N = self.M
+        else:
+            x = np.ascontiguousarray(target_points, dtype=self._host_dtype)
+            self.N = x.shape[0]
+        if self._ctx is None:
+            self._ctx = _lib.Context(self.device)
+            for key, value in self._options.items():
+                if value:
+                    self._ctx.set_option(key, value)
+        world = 1 if self.comm is None else self.comm.world
+        if world > 1:
+            # every rank keeps all targets and one contiguous slice of the sources
+            self._shard = sharding.shard_range(self.M, self.comm.rank, world)
+            lo, hi = self._shard
+            self.comm.attach(self._ctx)
+            self._ctx.set_points(np.ascontiguousarray(y[lo:hi]), y if x is None else x,
+                                 self._dtype_code, j_offset=lo, M_total=self.M)
+        else:
+            self._shard = (0, self.M)
+            self._ctx.set_points(y, x, self._dtype_code)
+
+    def prepare_query(self, *, source_signal):
+        if self.density_estimation:
+            self._ctx.set_signal(None)
+            self.E = 1
+            return
+        b = np.ascontiguousarray(source_signal, dtype=self._host_dtype)
+        if b.ndim == 1:
+            b = b.reshape(-1, 1)
+        self.E = b.shape[1]
+        lo, hi = self._shard
+        self._ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
+
+    def get_result(self):
+        return self._ctx.get_result(self.N, self.E)
+
+    # -- timed ---------------------------------------------------------------------
+    def fit(self):
+        """Nothing to pre-compute: the kernel matrix is never formed."""
+
+    def query(self):
+        # synchronous: the device (and the all-reduce) is done when this returns
+        self._ctx.run(self.kernel, self.normalize_rows)
+        self.res = None  # the result stays on the device until get_result()
+
+    # -- bookkeeping ---------------------------------------------------------------
+    def set_query_arguments(self, **kwargs):
+        for key, value in kwargs.items():
+            self._ctx.set_option(key, value)
+
+    def get_memory_usage(self):
+        """Device kB held by the context (the RSS of the reference says nothing here)."""
+        return 0.0 if self._ctx is None else self._ctx.device_bytes / 1024
+
+    def get_additional(self):
+        if self._ctx is None:
+            return {}
+        return {
+            "device_kernel_ms": self._ctx.last_kernel_ms,
+            "device_total_ms": self._ctx.last_total_ms,
+            "device_kernel": self._ctx.last_kernel_name,
+            "n_gpus": 1 if self.comm is None else self.comm.world,
+        }
+
+    def done(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def __del__(self):
+        # the runner calls done() only on the best instance (runner.py:174-176)
+        try:
+            self.done()
+        except Exception:
+            pass
+
+
+class MI355XSolver(BaseSolver):
+    """Solves K b = a by conjugate gradients with the HIP product as the operator."""
+
+    def __init__(self, *, kernel, dimension, normalize_rows=False, precision=np.float64,
+                 device=0, rtol=1e-6, maxit=1000):
+        super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows,
+                         precision=precision)
+        if kernel not in ("gaussian", "absolute-exponential"):
+            # inverse-distance with a zeroed diagonal is indefinite: CG does not apply
+            raise NotImplementedError(f"MI355XSolver doesn't support kernel {kernel}.")
+        self._dtype_code, self._host_dtype = _lib.dtype_code(precision)
+        if self._dtype_code == _lib.KMVP_BF16:
+            raise NotImplementedError("MI355XSolver needs float32 or float64")
+        self.device = device
+        self.rtol = rtol
+        self.maxit = maxit
+        self._ctx = None
+        self.iterations = 0
+        self.residual = float("nan")
+        self.converged = False
+        self.name = f"MI355XSolver({_precision_name(precision)}, rtol={rtol:g})"
+
+    def prepare_data(self, *, source_points):
+        y = np.ascontiguousarray(source_points, dtype=self._host_dtype)
+        self.M, self.D = y.shape
+        if self._ctx is None:
+            self._ctx = _lib.Context(self.device)
+        self._ctx.set_points(y, None, self._dtype_code)
+
+    def fit(self):
+        """Nothing to factorise."""
+
+    def prepare_query(self, *, target_signal):
+        a = np.ascontiguousarray(target_signal, dtype=self._host_dtype)
+        self._a = a.reshape(-1, 1) if a.ndim == 1 else a
+
+    def set_query_arguments(self, rtol=None, maxit=None):
+        if rtol is not None:
+            self.rtol = rtol
+        if maxit is not None:
+            self.maxit = maxit
+
+    def query(self):
+        self.res, self.iterations, self.residual, self.converged = self._ctx.cg_solve(
+            self.kernel, self._a, self.rtol, self.maxit)
+
+    def get_memory_usage(self):
+        return 0.0 if self._ctx is None else self._ctx.device_bytes / 1024
+
+    def get_additional(self):
+        return {"cg_iterations": self.iterations, "cg_relative_residual": self.residual,
+                "cg_converged": bool(self.converged)}
+
+    def done(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.done()
+        except Exception:
+            pass

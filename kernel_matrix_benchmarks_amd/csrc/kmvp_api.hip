@@ -97,7 +97,7 @@ struct kmvp_ctx {
   int out_e = 0;
 
   // tuning (kmvp_set_option)
-  int opt_feed = 0, opt_T = 0, opt_segments = 0, opt_chunk = 512;
+  int opt_feed = -1, opt_T = 0, opt_segments = 0, opt_chunk = 512;
 
   // sharding
   ncclComm_t comm = nullptr;
@@ -286,8 +286,8 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (specialised) {
     LowdTuning tune;
-    tune.targets_per_lane = c->opt_T > 0 ? c->opt_T : default_targets_per_lane(D);
-    tune.feed = c->opt_feed;
+    tune.feed = c->opt_feed >= 0 ? c->opt_feed : DEFAULT_FEED;
+    tune.targets_per_lane = c->opt_T > 0 ? c->opt_T : (tune.feed == 1 ? DEFAULT_TARGETS_PER_LANE : 2);
     const int T = tune.targets_per_lane;
     const int EB = sig == SIG_DENSITY ? 0 : E;
     const int R = (D + EB + 3) / 4 * 4;
@@ -348,8 +348,6 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   } else {
     // generic fallback: scaled copies of the points, one target per lane
     n_pad = round_up(std::max<int64_t>(N, 1), BLOCK_THREADS);
-    if ((size_t)D * BLOCK_THREADS * sizeof(real) > 160 * 1024)
-      return fail(c, KMVP_E_UNSUPPORTED, "point dimension too large for the generic kernel");
     if (c->gen_points_ver != c->points_ver || c->gen_kernel != kernel) {
       if ((rc = ensure(c, c->y_scaled, (size_t)M * D * sizeof(real)))) return rc;
       hipLaunchKernelGGL((scale_kernel<real>), dim3(blocks_for(M * D)), dim3(256), 0, c->stream,
@@ -799,7 +797,7 @@ int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return KMVP_E_INVALID;
   const std::string k(key);
   if (k == "feed") {
-    if (value != 0 && value != 1) return fail(c, KMVP_E_INVALID, "feed must be 0 or 1");
+    if (value < -1 || value > 1) return fail(c, KMVP_E_INVALID, "feed must be -1 (auto), 0 or 1");
     c->opt_feed = (int)value;
   } else if (k == "targets_per_lane") {
     if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)

@@ -18,8 +18,9 @@ struct LowdTuning {
 constexpr int LOWD_MAX_D = 8;
 constexpr int LOWD_MAX_E = 4;
 
-// default T for a point dimension (register budget: T*(D+NE) VGPRs of state)
-inline int default_targets_per_lane(int D) { return D <= 4 ? 4 : 2; }
+// defaults, from the sweep on MI355X (profiles/): one target per lane, LDS-staged tiles
+constexpr int DEFAULT_TARGETS_PER_LANE = 1;
+constexpr int DEFAULT_FEED = 1;
 
 // Returns hipErrorInvalidValue when (D, E, sig, tuning) has no instantiation.
 // One function per kernel x precision: each lives in its own translation unit

@@ -353,14 +353,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
     const real* __restrict__ b,  // (M,E) row-major or null
     double* __restrict__ part,   // [segments][NE][n_pad]
     int64_t n, int64_t n_pad, int64_t m, int D, int E, int NE, int segments, int64_t seg_len,
-    int64_t j_offset, int64_t m_total) {
+    int64_t j_offset, int64_t m_total, int x_in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  real* xl = reinterpret_cast<real*>(dyn_lds);  // [D][BLOCK_THREADS]
+  real* xl = reinterpret_cast<real*>(dyn_lds);  // [D][BLOCK_THREADS] when it fits in LDS
   const int seg = (int)(blockIdx.x % segments);
   const int64_t tb = blockIdx.x / segments;
   const int64_t i = tb * BLOCK_THREADS + threadIdx.x;
   const int64_t ic = i < n ? i : n - 1;
-  for (int d = 0; d < D; ++d) xl[d * BLOCK_THREADS + threadIdx.x] = x[ic * D + d];
+  if (x_in_lds)
+    for (int d = 0; d < D; ++d) xl[d * BLOCK_THREADS + threadIdx.x] = x[ic * D + d];
+  const real* __restrict__ xrow = x + ic * D;
   int64_t jz = -1;
   if constexpr (KERNEL == K_INVDIST) {
     const int64_t g = ic % (m_total + 1);
@@ -376,9 +378,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
     for (int q = 0; q < 8; ++q) acc[q] = 0.0;
     for (int64_t j = j0; j < j1; ++j) {
       real s = 0;
-      for (int d = 0; d < D; ++d) {
-        const real df = xl[d * BLOCK_THREADS + threadIdx.x] - y[j * D + d];
-        s = fma(df, df, s);
+      if (x_in_lds) {
+        for (int d = 0; d < D; ++d) {
+          const real df = xl[d * BLOCK_THREADS + threadIdx.x] - y[j * D + d];
+          s = fma(df, df, s);
+        }
+      } else {
+        for (int d = 0; d < D; ++d) {
+          const real df = xrow[d] - y[j * D + d];
+          s = fma(df, df, s);
+        }
       }
       real k = kval<KERNEL>(s);
       if constexpr (KERNEL == K_INVDIST) k = (j == jz) ? (real)0 : k;

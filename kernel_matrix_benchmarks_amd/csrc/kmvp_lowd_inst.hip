@@ -26,23 +26,22 @@ static hipError_t launch_one(const LowdArgs<real>& args, dim3 grid, hipStream_t 
   return hipGetLastError();
 }
 
-// T / FEED variants: every shape gets its default T with the scalar-cache feed; the
-// headline shape (D=3, E=1) additionally gets the whole tuning grid so that the
-// choice is made from measurements, not guesses.
+// T / FEED variants: every shape gets (T=1, LDS feed) -- the measured best and the
+// default -- and (T=2, scalar-cache feed); the headline shape (D=3, E=1) additionally
+// gets the whole tuning grid so that the choice stays backed by measurements.
 template <int D, int E, int SIG>
 static hipError_t launch_te(LowdTuning tune, const LowdArgs<real>& args, dim3 grid,
                             hipStream_t stream, const char** kernel_name) {
-  constexpr int TD = (D <= 4) ? 4 : 2;
-  if (tune.feed == 0 && tune.targets_per_lane == TD)
-    return launch_one<D, E, SIG, TD, 0>(args, grid, stream, kernel_name);
+  const int T = tune.targets_per_lane, F = tune.feed;
+  if (F == 1 && T == 1) return launch_one<D, E, SIG, 1, 1>(args, grid, stream, kernel_name);
+  if (F == 0 && T == 2) return launch_one<D, E, SIG, 2, 0>(args, grid, stream, kernel_name);
   if constexpr (D == 3 && E == 1) {
-    if (tune.feed == 0 && tune.targets_per_lane == 1) return launch_one<D, E, SIG, 1, 0>(args, grid, stream, kernel_name);
-    if (tune.feed == 0 && tune.targets_per_lane == 2) return launch_one<D, E, SIG, 2, 0>(args, grid, stream, kernel_name);
-    if (tune.feed == 0 && tune.targets_per_lane == 8) return launch_one<D, E, SIG, 8, 0>(args, grid, stream, kernel_name);
-    if (tune.feed == 1 && tune.targets_per_lane == 1) return launch_one<D, E, SIG, 1, 1>(args, grid, stream, kernel_name);
-    if (tune.feed == 1 && tune.targets_per_lane == 2) return launch_one<D, E, SIG, 2, 1>(args, grid, stream, kernel_name);
-    if (tune.feed == 1 && tune.targets_per_lane == 4) return launch_one<D, E, SIG, 4, 1>(args, grid, stream, kernel_name);
-    if (tune.feed == 1 && tune.targets_per_lane == 8) return launch_one<D, E, SIG, 8, 1>(args, grid, stream, kernel_name);
+    if (F == 0 && T == 1) return launch_one<D, E, SIG, 1, 0>(args, grid, stream, kernel_name);
+    if (F == 0 && T == 4) return launch_one<D, E, SIG, 4, 0>(args, grid, stream, kernel_name);
+    if (F == 0 && T == 8) return launch_one<D, E, SIG, 8, 0>(args, grid, stream, kernel_name);
+    if (F == 1 && T == 2) return launch_one<D, E, SIG, 2, 1>(args, grid, stream, kernel_name);
+    if (F == 1 && T == 4) return launch_one<D, E, SIG, 4, 1>(args, grid, stream, kernel_name);
+    if (F == 1 && T == 8) return launch_one<D, E, SIG, 8, 1>(args, grid, stream, kernel_name);
   }
   return hipErrorInvalidValue;
 }
@@ -98,23 +97,25 @@ hipError_t KMVP_CAT(KMVP_FN, _generic)(int sig, const real* x, const real* y, co
                                        int64_t j_offset, int64_t m_total, hipStream_t stream,
                                        const char** kernel_name) {
   const dim3 grid((unsigned)((n_pad / BLOCK_THREADS) * segments));
-  const size_t lds = (size_t)D * BLOCK_THREADS * sizeof(real);
+  size_t lds = (size_t)D * BLOCK_THREADS * sizeof(real);
+  const int x_in_lds = lds <= 64 * 1024 ? 1 : 0;  // larger D: the target row is re-read through L1
+  if (!x_in_lds) lds = 0;
   if (kernel_name) *kernel_name = "lowd_generic_kernel";
   switch (sig) {
     case SIG_PRODUCT:
       hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_PRODUCT, real>), grid, dim3(BLOCK_THREADS),
                          lds, stream, x, y, b, part, n, n_pad, m, D, E, NE, segments, seg_len,
-                         j_offset, m_total);
+                         j_offset, m_total, x_in_lds);
       break;
     case SIG_NORM:
       hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_NORM, real>), grid, dim3(BLOCK_THREADS),
                          lds, stream, x, y, b, part, n, n_pad, m, D, E, NE, segments, seg_len,
-                         j_offset, m_total);
+                         j_offset, m_total, x_in_lds);
       break;
     case SIG_DENSITY:
       hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_DENSITY, real>), grid,
                          dim3(BLOCK_THREADS), lds, stream, x, y, b, part, n, n_pad, m, D, E, NE,
-                         segments, seg_len, j_offset, m_total);
+                         segments, seg_len, j_offset, m_total, x_in_lds);
       break;
     default:
       return hipErrorInvalidValue;

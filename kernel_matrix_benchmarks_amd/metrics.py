@@ -1,0 +1,59 @@
+"""Error / time metrics, counterpart of ``kernel_matrix_benchmarks/plotting/metrics.py``.
+
+``result_errors`` restates metrics.py:36-61 (per-row L2 norm over the E columns of
+``error``, then max / mean / median / rmse); the time metrics restate :67-81.
+``max-error`` is the "max |err|" of BASELINE.json's metric.
+"""
+import numpy as np
+
+
+def result_errors(error):
+    norms = np.sqrt(np.sum(np.asarray(error, dtype=np.float64) ** 2, axis=-1))
+    return {
+        "max": float(np.max(norms)),
+        "mean": float(np.mean(norms)),
+        "median": float(np.median(norms)),
+        "rmse": float(np.sqrt(np.mean(norms ** 2))),
+    }
+
+
+def relative_max_error(result, truth):
+    """max_i ||result_i - truth_i|| / max_i ||truth_i|| -- the tolerance the parity
+    tests state (the reference defines no threshold)."""
+    result = np.asarray(result, dtype=np.float64)
+    truth = np.asarray(truth, dtype=np.float64)
+    scale = np.max(np.sqrt(np.sum(truth ** 2, axis=-1)))
+    return result_errors(result - truth)["max"] / (scale if scale > 0 else 1.0)
+
+
+def build_time(properties):
+    return properties["build_time"]
+
+
+def query_time(properties):
+    return properties["query_time"]
+
+
+def total_time(properties):
+    return properties["build_time"] + properties["query_time"]
+
+
+def memory_footprint(properties):
+    return properties.get("memory_footprint", 0)
+
+
+def pairs_per_second(properties, n_targets, n_sources):
+    """N*M / (build + query): the headline throughput."""
+    return float(n_targets) * float(n_sources) / total_time(properties)
+
+
+ALL_METRICS = {
+    "max-error": lambda error, properties: result_errors(error)["max"],
+    "mean-error": lambda error, properties: result_errors(error)["mean"],
+    "median-error": lambda error, properties: result_errors(error)["median"],
+    "rmse-error": lambda error, properties: result_errors(error)["rmse"],
+    "build-time": lambda error, properties: build_time(properties),
+    "query-time": lambda error, properties: query_time(properties),
+    "total-time": lambda error, properties: total_time(properties),
+    "memory-footprint": lambda error, properties: memory_footprint(properties),
+}

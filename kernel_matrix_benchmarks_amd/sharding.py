@@ -1,0 +1,60 @@
+"""Source sharding over the GPUs of one node.
+
+One process per GPU.  Rank r owns the contiguous source slice
+``shard_range(M, r, world)`` and all targets; the (N, E[+1]) partial sums are
+summed with ONE RCCL all-reduce inside ``libkmvp.so`` (``kmvp_comm_init`` /
+``ncclAllReduce`` on the context's stream).  This module only does the host-side
+bookkeeping: the slice arithmetic and handing the 128-byte RCCL unique id from
+rank 0 to the other ranks through an out-of-band channel.
+
+The reference has no distributed code at all; nothing here mirrors a
+reference file.
+"""
+
+
+def shard_range(M, rank, world):
+    """Contiguous [lo, hi) of the M sources owned by ``rank``; sizes differ by <= 1."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, extra = divmod(int(M), world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+class Communicator:
+    """Binds contexts of this process to an RCCL communicator.
+
+    ``broadcast_bytes(payload_or_None) -> bytes`` must return rank 0's payload on
+    every rank (e.g. ``torch.distributed.broadcast_object_list`` over gloo, or an
+    MPI bcast); it is only used to distribute the RCCL unique id.
+    """
+
+    def __init__(self, rank, world, broadcast_bytes):
+        self.rank = int(rank)
+        self.world = int(world)
+        self._broadcast = broadcast_bytes
+        self._attached = set()
+
+    def attach(self, ctx):
+        from kernel_matrix_benchmarks_amd import _lib
+
+        if id(ctx) in self._attached or self.world == 1:
+            return
+        uid = _lib.comm_unique_id() if self.rank == 0 else None
+        uid = self._broadcast(uid)
+        ctx.comm_init(uid, self.rank, self.world)
+        self._attached.add(id(ctx))
+
+
+def torch_gloo_communicator():
+    """Communicator over an initialised ``torch.distributed`` process group (any
+    backend that can broadcast Python objects from the host, i.e. gloo)."""
+    import torch.distributed as dist
+
+    def bcast(payload):
+        box = [payload]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    return Communicator(dist.get_rank(), dist.get_world_size(), bcast)

@@ -1,0 +1,221 @@
+"""CPU tests: the C-ABI library loads and exports what include/kmvp.h declares; host
+logic (registry, file names, sharding arithmetic, runner protocol, containers).
+No compute call is made here -- there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import golden_cases
+import kmvp_oracle
+from kernel_matrix_benchmarks_amd import _lib, datasets, definitions, metrics, results, runner, sharding, storage
+from kernel_matrix_benchmarks_amd.algorithms import base, mi355x
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "kmvp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmvp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"libkmvp.so lacks {name}"
+    assert sorted(s[0] for s in _lib.SYMBOLS) == names, "binding table and header disagree"
+    assert lib.kmvp_abi_version() == 1
+
+
+def test_library_is_the_hip_build():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob, "libkmvp.so carries no gfx950 code object"
+    assert b"lowd_kernel" in blob
+
+
+def test_no_product_code_touches_the_oracle():
+    pkg = os.path.join(ROOT, "kernel_matrix_benchmarks_amd")
+    for d, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(d, fn)).read()
+                assert "kmvp_oracle" not in text and "c_oracle" not in text, fn
+
+
+def test_constructor_contract():
+    with pytest.raises(NotImplementedError):  # bruteforce.py:82-85
+        mi355x.MI355XProduct(kernel="laplacian", dimension=3)
+    with pytest.raises(NotImplementedError):
+        mi355x.MI355XSolver(kernel="inverse-distance", dimension=3)
+    with pytest.raises(NotImplementedError):
+        mi355x.MI355XProduct(kernel="gaussian", dimension=3, precision="float16")
+    p = mi355x.MI355XProduct(kernel="gaussian", dimension=3, normalize_rows=True, precision="float32")
+    assert p.task == "product" and str(p) == "MI355XProduct(float32)" and p.normalize_rows
+    assert isinstance(p, base.BaseProduct) and p.get_additional() == {} and p.get_memory_usage() == 0.0
+    s = mi355x.MI355XSolver(kernel="gaussian", dimension=3, precision=np.float64)
+    assert s.task == "solver" and isinstance(s, base.BaseSolver)
+    p.done()
+    s.done()
+
+
+def test_no_gpu_means_a_loud_failure_not_a_fallback():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = mi355x.MI355XProduct(kernel="gaussian", dimension=3)
+    y = np.random.rand(8, 3)
+    with pytest.raises(_lib.KmvpError):
+        p.prepare_data(source_points=y, target_points=y, same_points=True)
+
+
+def test_registry_expansion_rules():
+    defs = definitions.get_definitions(dataset="product-cube-D3-E1-M1000-N1000-gaussian")
+    assert [d.arguments["precision"] for d in defs] == ["float32", "float64"]
+    d = defs[0]
+    assert d.arguments["kernel"] == "gaussian" and d.arguments["dimension"] == 3
+    assert d.arguments["normalize_rows"] is False and d.query_argument_groups == [{}]
+    assert definitions.algorithm_available(d)
+    assert definitions.get_definitions(hardware="CPU") == []
+    sol = definitions.get_definitions(task="solver", dataset="solver-cube-D3-E1-M1000-N1000-gaussian")
+    assert [s.constructor for s in sol] == ["MI355XSolver"] * 2
+    assert definitions.get_definitions(task="solver", dataset="solver-sphere-D3-E1-M1000-N1000-inverse-distance") == []
+    att = definitions.get_definitions(task="attention", normalize_rows=True)
+    assert att and all(a.arguments["normalize_rows"] for a in att)
+
+
+def test_result_filename_rule():
+    d = definitions.Definition("algo-x", "C", "m", "t", {"kernel": "gaussian", "dimension": 3,
+                                                         "normalize_rows": np.bool_(False), "precision": "float32"}, [{}])
+    fn = results.result_filename("ds", d, {"h": 3}, root="results")
+    # results.py:73-93: json.dumps(sorted) with every run of non-word characters -> "_"
+    assert fn == os.path.join("results", "ds", "algo-x",
+                              "dimension_3_h_3_kernel_gaussian_normalize_rows_false_precision_float32" + storage.extension())
+
+
+def test_dataset_names_and_generators():
+    p = datasets.parse_name("product-cube-D3-E1-M1000000-N1000000-gaussian")
+    assert (p["task"], p["label"], p["D"], p["E"], p["M"], p["N"], p["kernel"]) == (
+        "product", "cube", 3, 1, 1000000, 1000000, "gaussian")
+    p = datasets.parse_name("solver-sphere-D3-E1-M1000-N1000-inverse-distance")
+    assert p["kernel"] == "inverse-distance" and p["task"] == "solver"
+    with pytest.raises(ValueError):
+        datasets.parse_name("glove-25-angular")
+    y, b = datasets.cube_points(100, 3)
+    yo, bo = kmvp_oracle.uniform_cube(100, 3)
+    assert np.array_equal(y, yo) and np.array_equal(b, bo)
+    np.testing.assert_allclose(datasets.sphere_points(10), kmvp_oracle.uniform_sphere_points(10), atol=1e-15)
+    s = datasets.sphere_points(1000)
+    np.testing.assert_allclose(np.linalg.norm(s, axis=1), 1.0, atol=1e-12)
+
+
+def test_shard_ranges_partition_the_sources():
+    for M in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            parts = [sharding.shard_range(M, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == M
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 2, 2)
+
+
+def test_container_roundtrip(tmp_path):
+    fn = str(tmp_path / ("roundtrip" + storage.extension()))
+    a = np.arange(12.0).reshape(4, 3)
+    with storage.open_file(fn, "w") as f:
+        f["a"] = a
+        f.attrs["kernel"] = "gaussian"
+        f.attrs["same_points"] = True
+        f.attrs["build_time"] = 0.25
+        f.attrs["run_count"] = 2
+    f = storage.open_file(fn, "r")
+    try:
+        assert np.array_equal(np.asarray(f["a"][:]), a)
+        k = f.attrs["kernel"]
+        assert (k.decode() if isinstance(k, bytes) else k) == "gaussian"
+        assert bool(f.attrs["same_points"]) is True
+        assert float(f.attrs["build_time"]) == 0.25 and int(f.attrs["run_count"]) == 2
+    finally:
+        f.close()
+
+
+def test_metrics_definition():
+    err = np.array([[3.0, 4.0], [0.0, 0.0], [1.0, 0.0]])
+    m = metrics.result_errors(err)
+    assert m == kmvp_oracle.result_errors(err)
+    props = {"build_time": 1.0, "query_time": 3.0}
+    assert metrics.total_time(props) == 4.0 and metrics.pairs_per_second(props, 10, 20) == 50.0
+    assert metrics.ALL_METRICS["max-error"](err, props) == 5.0
+
+
+class OracleBackedProduct(base.BaseProduct):
+    """TEST-ONLY plugin (lives in tests/): lets the runner protocol be exercised on a
+    machine without a GPU.  Not part of the product."""
+
+    calls = []
+
+    def __init__(self, *, kernel, dimension, normalize_rows=False, precision="float64"):
+        super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows, precision=precision)
+        self.name = f"OracleBackedProduct({precision})"
+        OracleBackedProduct.calls.append("init")
+
+    def prepare_data(self, *, source_points, target_points, same_points=False, density_estimation=False):
+        self.y, self.x, self.de = source_points, (None if same_points else target_points), density_estimation
+        OracleBackedProduct.calls.append("prepare_data")
+
+    def fit(self):
+        OracleBackedProduct.calls.append("fit")
+
+    def prepare_query(self, *, source_signal):
+        self.b = source_signal
+        OracleBackedProduct.calls.append("prepare_query")
+
+    def query(self):
+        self.res = kmvp_oracle.product(kernel=self.kernel, source_points=self.y, target_points=self.x,
+                                       source_signal=self.b, normalize_rows=self.normalize_rows,
+                                       density_estimation=self.de, precision=self.precision)
+        OracleBackedProduct.calls.append("query")
+
+    def done(self):
+        OracleBackedProduct.calls.append("done")
+
+
+def test_runner_protocol_and_result_files(tmp_path):
+    name = "product-cube-D3-E1-M200-N200-gaussian"
+    y, b = datasets.cube_points(200, 3)
+    truth = kmvp_oracle.product(kernel="gaussian", source_points=y, source_signal=b)
+    data_root = str(tmp_path / "data")
+    datasets.write_dataset(filename=datasets.dataset_path(name, data_root), task="product", kernel="gaussian",
+                           source_points=y, source_signal=b, target_signal=truth)
+    yaml_file = tmp_path / "algos.yaml"
+    yaml_file.write_text(
+        "oracle-backed:\n  hardware: CPU\n  product: true\n  docker-tag: none\n"
+        "  module: test_abi_and_host\n  constructor: OracleBackedProduct\n  run-groups:\n    g:\n"
+        "      datasets: ['*-gaussian']\n      args: [{precision: float64}, {precision: float32}]\n")
+    OracleBackedProduct.calls.clear()
+    out = runner.run_dataset(name, hardware="CPU", runs=2, definition_file=str(yaml_file),
+                             data_root=data_root, results_root=str(tmp_path / "results"), verbose=False)
+    assert len(out) == 2
+    # runner.py:70-148: fresh instance per fit run, prepare_query before every query run
+    one = ["init", "prepare_data", "fit"] * 2
+    assert OracleBackedProduct.calls[:6] == one
+    assert OracleBackedProduct.calls.count("query") == 4 and OracleBackedProduct.calls.count("prepare_query") == 4
+    assert OracleBackedProduct.calls.count("done") >= 2
+    loaded = list(results.load_all_results(name, root=str(tmp_path / "results")))
+    assert len(loaded) == 2
+    for (fn, attrs, result) in out:
+        assert os.path.exists(fn)
+        for key in ("dataset", "algo", "name", "kernel", "run_count", "build_time", "query_time", "memory_footprint"):
+            assert key in attrs  # runner.py:151-163
+        assert attrs["algo"] == "oracle-backed" and attrs["run_count"] == 2
+    f = storage.open_file(out[0][0], "r")
+    try:
+        err = np.asarray(f["error"][:])
+        assert metrics.result_errors(err)["max"] < 1e-12  # fp64 run reproduces the dataset
+    finally:
+        f.close()

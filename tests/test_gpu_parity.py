@@ -1,0 +1,289 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+plugin classes and the C ABI, against the reference's outputs (golden fixtures), the
+oracle, and size-independent properties at the benchmark's full size.
+
+Tolerances (stated once, used everywhere):
+  float64  rel <= 1e-11  (same arithmetic as the reference's truth, other summation order)
+  float32  rel <= max(1e-5, 2 x the error of the REFERENCE's own float32 run)
+           -- 1e-5 is the north-star tolerance; rel = max_i ||err_i|| / max_i ||a_i||
+           (metrics.py:53-56 norm, made relative).
+Rows that are non-finite in the reference (coincident off-diagonal points under
+inverse-distance, bruteforce.py:8-15) must be non-finite here too.
+"""
+import numpy as np
+import pytest
+
+import c_oracle
+import golden_cases
+import kmvp_oracle
+from conftest import rel_err
+from kernel_matrix_benchmarks_amd import _lib
+from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct, MI355XSolver
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_cases.product_cases()
+IDS = [c["name"] for c in CASES]
+TOL64 = 1e-11
+TOL32 = 1e-5
+
+
+def run_plugin(case, y, x, b, precision, **options):
+    """The runner's call order, runner.py:70-148."""
+    algo = MI355XProduct(kernel=case["kernel"], dimension=case["D"],
+                         normalize_rows=case.get("normalize_rows", False), precision=precision, **options)
+    try:
+        algo.prepare_data(source_points=y, target_points=(y if x is None else x),
+                          same_points=np.bool_(x is None),
+                          density_estimation=np.bool_(b is None))
+        algo.fit()
+        algo.prepare_query(source_signal=(np.ones((len(y), 1)) if b is None else b))
+        algo.query()
+        out = algo.get_result()
+        extra = algo.get_additional()
+        assert algo.get_memory_usage() > 0
+    finally:
+        algo.done()
+    assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"]
+    return out, extra
+
+
+def row_finite(a):
+    return np.isfinite(a).all(axis=-1)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_float64_matches_reference(case, expected):
+    y, x, b = golden_cases.make_inputs(case)
+    want = expected[f"{case['name']}/f64"]
+    got, _ = run_plugin(case, y, x, b, np.float64)
+    assert got.shape == want.shape
+    assert np.array_equal(row_finite(got), row_finite(want)), "non-finite rows differ"
+    assert rel_err(got, want) <= TOL64, rel_err(got, want)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_float32_matches_reference(case, expected):
+    y, x, b = golden_cases.make_inputs(case)
+    truth = expected[f"{case['name']}/f64"]
+    ref32 = expected[f"{case['name']}/f32"].astype(np.float64)
+    got, extra = run_plugin(case, y, x, b, "float32")  # precision arrives as a string, algos.yaml:157
+    assert got.shape == truth.shape
+    assert np.array_equal(row_finite(got), row_finite(truth)), "non-finite rows differ"
+    tol = max(TOL32, 2 * rel_err(ref32, truth))
+    assert rel_err(got, truth) <= tol, (rel_err(got, truth), tol)
+    assert extra["n_gpus"] == 1 and extra["device_kernel"]
+
+
+def test_every_tuning_variant_gives_the_same_answer(expected):
+    case = next(c for c in CASES if c["name"] == "gaussian-N257-M193-D3-E1")
+    y, x, b = golden_cases.make_inputs(case)
+    want = expected[f"{case['name']}/f64"]
+    for kernel in golden_cases.KERNELS:
+        c = dict(case, kernel=kernel)
+        want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b)
+        for feed in (0, 1):
+            for T in (1, 2, 4, 8):
+                for seg in (0, 1, 3, 8):
+                    got, _ = run_plugin(c, y, x, b, np.float32, feed=feed if feed else None,
+                                        targets_per_lane=T, segments=seg)
+                    assert rel_err(got, want) <= TOL32, (kernel, feed, T, seg, rel_err(got, want))
+        got, _ = run_plugin(c, y, x, b, np.float32, chunk=8)
+        assert rel_err(got, want) <= TOL32
+
+
+def test_results_are_bitwise_reproducible():
+    y, b = kmvp_oracle.uniform_cube(5000, 3)
+    case = dict(kernel="gaussian", D=3)
+    a1, _ = run_plugin(case, y, None, b, np.float32)
+    a2, _ = run_plugin(case, y, None, b, np.float32)
+    assert np.array_equal(a1, a2)  # no atomics: fixed summation order
+
+
+def test_source_shard_with_global_offset_matches_oracle():
+    """What one rank computes when the sources are sharded (kmvp_set_points j_offset / M_total)."""
+    case = dict(N=300, M=257, D=3, E=2, seed=11, same_points=False, density_estimation=False)
+    y, x, b = golden_cases.make_inputs(case)
+    for kernel in golden_cases.KERNELS:
+        total = np.zeros((300, 2))
+        for lo, hi in ((0, 130), (130, 257)):
+            ctx = _lib.Context(0)
+            try:
+                ctx.set_points(np.ascontiguousarray(y[lo:hi]), x, _lib.KMVP_F64, j_offset=lo, M_total=257)
+                ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
+                ctx.run(kernel, False)
+                part = ctx.get_result(300, 2)
+            finally:
+                ctx.close()
+            want, _ = kmvp_oracle.product(kernel=kernel, source_points=y[lo:hi], target_points=x,
+                                          source_signal=b[lo:hi], j_offset=lo, M_total=257, raw_sums=True)
+            assert rel_err(part, want) <= TOL64, (kernel, lo)
+            total += part
+        full = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b)
+        assert rel_err(total, full) <= TOL64
+
+
+def test_single_rank_rccl_communicator():
+    """kmvp_comm_get_unique_id / kmvp_comm_init / ncclAllReduce with world == 1 on the one GPU."""
+    y, b = kmvp_oracle.uniform_cube(1000, 3)
+    ctx = _lib.Context(0)
+    try:
+        ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+        ctx.set_points(y.astype(np.float32), None, _lib.KMVP_F32)
+        ctx.set_signal(b.astype(np.float32))
+        ctx.run("gaussian", True)
+        got = ctx.get_result(1000, 1)
+    finally:
+        ctx.close()
+    want = kmvp_oracle.product(kernel="gaussian", source_points=y, source_signal=b, normalize_rows=True)
+    assert rel_err(got, want) <= TOL32
+
+
+def test_abi_error_behaviour():
+    ctx = _lib.Context(0)
+    try:
+        with pytest.raises(_lib.KmvpError):  # no points yet
+            ctx.run("gaussian", False)
+        y = np.random.rand(10, 3).astype(np.float32)
+        ctx.set_points(y, None, _lib.KMVP_F32)
+        with pytest.raises(_lib.KmvpError):  # no signal yet
+            ctx.run("gaussian", False)
+        with pytest.raises(_lib.KmvpError):
+            ctx.set_option("no-such-option", 1)
+        with pytest.raises(_lib.KmvpError):
+            ctx.set_option("targets_per_lane", 3)
+        ctx.set_signal(np.ones((10, 1), dtype=np.float32))
+        ctx.run("gaussian", False)
+        assert ctx.get_result(10, 1).shape == (10, 1)
+    finally:
+        ctx.close()
+    with pytest.raises(_lib.KmvpError):
+        _lib.Context(10 ** 6)
+
+
+def test_inputs_are_never_modified():
+    y, b = kmvp_oracle.uniform_cube(500, 3)
+    y0, b0 = y.copy(), b.copy()
+    run_plugin(dict(kernel="inverse-distance", D=3), y, None, b, np.float32)
+    assert np.array_equal(y, y0) and np.array_equal(b, b0)
+
+
+# ---- the benchmark's full size: row subset against the oracle + size-independent properties
+
+def test_config2_gaussian_1e6_row_subset_and_properties():
+    n = 1_000_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)  # BASELINE config 2, datasets.py:256-266 recipe
+    rows = np.random.RandomState(0).choice(n, size=1024, replace=False)
+    algo = MI355XProduct(kernel="gaussian", dimension=3, precision="float32")
+    try:
+        algo.prepare_data(source_points=y, target_points=y, same_points=True)
+        algo.prepare_query(source_signal=b)
+        algo.query()
+        a = algo.get_result()
+        want = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=rows)
+        scale = np.max(np.abs(want))
+        assert np.max(np.abs(a[rows] - want)) / scale <= TOL32
+        # linearity: K(2b + c) = 2 Kb + Kc
+        c = np.random.RandomState(1).randn(n, 1)
+        algo.prepare_query(source_signal=c)
+        algo.query()
+        ac = algo.get_result()
+        algo.prepare_query(source_signal=2 * b + c)
+        algo.query()
+        a2 = algo.get_result()
+        assert np.max(np.abs(a2 - (2 * a + ac))) / np.max(np.abs(a2)) <= 4 * TOL32
+        # symmetry of K when x == y:  <c, K b> = <b, K c>
+        lhs, rhs = float(np.sum(c * a)), float(np.sum(b * ac))
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), np.linalg.norm(c) * np.linalg.norm(a) * 1e-2)
+    finally:
+        algo.done()
+
+
+def test_config2_normalised_rows_are_convex_combinations():
+    n = 200_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    for kernel in golden_cases.KERNELS:
+        algo = MI355XProduct(kernel=kernel, dimension=3, normalize_rows=True, precision="float32")
+        try:
+            algo.prepare_data(source_points=y, target_points=y, same_points=True)
+            algo.prepare_query(source_signal=b)
+            algo.query()
+            a = algo.get_result()
+            assert a.min() >= b.min() - 1e-4 and a.max() <= b.max() + 1e-4
+            algo.prepare_data(source_points=y, target_points=y, same_points=True, density_estimation=True)
+            algo.prepare_query(source_signal=np.ones((n, 1)))
+            algo.query()
+            assert np.array_equal(algo.get_result(), np.ones((n, 1)))  # bruteforce.py:134-138
+        finally:
+            algo.done()
+
+
+def test_inverse_distance_1e6_row_subset_with_sharded_offsets():
+    """Config 4's kernel at 1e6, computed as 2 source shards on the one GPU."""
+    n = 1_000_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    rows = np.random.RandomState(2).choice(n, size=512, replace=False)
+    total = np.zeros((n, 1))
+    for lo, hi in ((0, n // 2 + 7), (n // 2 + 7, n)):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_points(np.ascontiguousarray(y[lo:hi], dtype=np.float32), y.astype(np.float32),
+                           _lib.KMVP_F32, j_offset=lo, M_total=n)
+            ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
+            ctx.run("inverse-distance", False)
+            total += ctx.get_result(n, 1)
+        finally:
+            ctx.close()
+    assert np.isfinite(total).all()  # the diagonal was zeroed by GLOBAL index in both shards
+    want = c_oracle.product(kernel="inverse-distance", source_points=y, source_signal=b, rows=rows)
+    assert np.max(np.abs(total[rows] - want)) / np.max(np.abs(want)) <= 2 * TOL32
+
+
+# ---- solver
+
+def test_cg_solver_reaches_the_residual(expected):
+    for case in golden_cases.solver_cases():
+        y, _ = golden_cases.make_solver_inputs(case)
+        a = expected[f"{case['name']}/a"]
+        algo = MI355XSolver(kernel=case["kernel"], dimension=3, precision=np.float64, rtol=1e-8, maxit=5000)
+        try:
+            algo.prepare_data(source_points=y)
+            algo.fit()
+            algo.prepare_query(target_signal=a)
+            algo.query()
+            sol = algo.get_result()
+            info = algo.get_additional()
+        finally:
+            algo.done()
+        assert sol.shape == a.shape and sol.dtype == np.float64
+        res = kmvp_oracle.relative_residual(kernel=case["kernel"], source_points=y, solution=sol, target_signal=a)
+        assert info["cg_converged"], (case["name"], info)
+        assert res <= 2e-8, (case["name"], res, info)
+        assert abs(res - info["cg_relative_residual"]) <= 1e-9
+
+
+def test_cg_solver_config5_shape_small():
+    """Config 5 recipe (gaussian, D=3, fp64, a := K b) at n = 20000: residual < 1e-6."""
+    n = 20000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    prod = MI355XProduct(kernel="gaussian", dimension=3, precision=np.float64)
+    try:
+        prod.prepare_data(source_points=y, target_points=y, same_points=True)
+        prod.prepare_query(source_signal=b)
+        prod.query()
+        a = prod.get_result()
+    finally:
+        prod.done()
+    algo = MI355XSolver(kernel="gaussian", dimension=3, precision=np.float64, rtol=1e-6, maxit=2000)
+    try:
+        algo.prepare_data(source_points=y)
+        algo.prepare_query(target_signal=a)
+        algo.query()
+        sol = algo.get_result()
+        info = algo.get_additional()
+    finally:
+        algo.done()
+    rows = np.random.RandomState(3).choice(n, size=256, replace=False)
+    Kb = c_oracle.product(kernel="gaussian", source_points=y, source_signal=sol, rows=rows)
+    assert info["cg_relative_residual"] <= 1e-6, info
+    assert np.linalg.norm(Kb - a[rows]) / np.linalg.norm(a[rows]) <= 5e-6

@@ -9,7 +9,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-constexpr int ITERS = 4096;
+constexpr int ITERS = 65536;
 
 template <int MODE>
 __global__ void __launch_bounds__(256) bench(float* out, float seed) {
@@ -23,18 +23,14 @@ __global__ void __launch_bounds__(256) bench(float* out, float seed) {
         a[i] = fmaf(a[i], b[i], 1.0f);
       } else if constexpr (MODE == 1) {  // 8 independent exp2 chains
         a[i] = __builtin_amdgcn_exp2f(a[i]);
-      } else if constexpr (MODE == 2) {  // pair-loop mix: 3 sub, mul, 2 fma, exp2, fma
-        float dx = a[i] - b[0], dy = a[i] - b[1], dz = a[i] - b[2];
+      } else if constexpr (MODE == 2 || MODE == 3) {
+        // pair-loop mix, exactly 3 sub, mul, 2 fma, 1 transcendental, fma per body.
+        // a[i] = x coordinate(s) of target i (reused for all 3 axes), source = SGPR values
+        const float sy0 = __builtin_amdgcn_readfirstlane(__float_as_int(seed + it * 1e-3f)) * 1e-9f;
+        float dx = a[i] - sy0, dy = a[i] - (sy0 + 1.0f), dz = a[i] - (sy0 + 2.0f);
         float s = dx * dx; s = fmaf(dy, dy, s); s = fmaf(dz, dz, s);
-        float k = __builtin_amdgcn_exp2f(-s);
-        b[i] = fmaf(k, b[3], b[i]);
-        a[i] += 1e-3f;                   // keeps the chain live (1 extra add per pair)
-      } else if constexpr (MODE == 3) {  // rsq mix (inverse distance)
-        float dx = a[i] - b[0], dy = a[i] - b[1], dz = a[i] - b[2];
-        float s = dx * dx; s = fmaf(dy, dy, s); s = fmaf(dz, dz, s);
-        float k = __builtin_amdgcn_rsqf(s);
-        b[i] = fmaf(k, b[3], b[i]);
-        a[i] += 1e-3f;
+        float k = MODE == 2 ? __builtin_amdgcn_exp2f(-s) : __builtin_amdgcn_rsqf(s);
+        b[i] = fmaf(k, sy0, b[i]);
       } else if constexpr (MODE == 4) {  // 7 fma : 1 exp, all independent
         float k = __builtin_amdgcn_exp2f(a[i]);
         float t = fmaf(a[i], b[i], 1.0f);
@@ -77,8 +73,8 @@ int main() {
     if (run<0>("fma x8 chains", 1, blocks)) return 1;
     if (run<1>("exp2 x8 chains", 1, blocks)) return 1;
     if (run<4>("7 fma + 1 exp2", 8, blocks)) return 1;
-    if (run<2>("gaussian pair mix (+1 add)", 1, blocks)) return 1;
-    if (run<3>("1/r pair mix (+1 add)", 1, blocks)) return 1;
+    if (run<2>("gaussian pair mix (8 ops/pair)", 1, blocks)) return 1;
+    if (run<3>("1/r pair mix (8 ops/pair)", 1, blocks)) return 1;
   }
   return 0;
 }
