@@ -248,20 +248,26 @@ __global__ void fill_kernel(double* p, int64_t n, double v) {
 
 unsigned blocks_for(int64_t n, int threads = 256) { return (unsigned)((n + threads - 1) / threads); }
 
-// number of source segments of a launch: enough blocks to keep 256 CUs x 8 blocks
-// busy for many rounds (tail effect), segments long enough to amortise the
-// prologue, partial buffer bounded.
+// Number of source segments of a launch (specialised kernels).  Three pulls:
+//  * L2 residency: with segments % 8 == 0 each XCD streams one segment at a time
+//    (block_to_work), so a segment of <= 2 MiB of records stays in its 4 MiB L2;
+//  * parallelism: tile_blocks * segments should be many rounds of the 2048 resident
+//    blocks (256 CUs x 8), which only matters when there are few target tiles;
+//  * the fp64 partial buffer segments * NE * n_pad * 8 bytes stays bounded.
 int choose_segments(const kmvp_ctx* c, int64_t tile_blocks, int64_t m_pad, int NE, int64_t n_pad,
-                    int64_t min_seg) {
+                    int64_t rec_bytes, int64_t min_seg) {
   int64_t seg;
   if (c->opt_segments > 0) {
     seg = c->opt_segments;
   } else {
+    const int64_t l2_seg_bytes = 2 << 20;
+    seg = 8 * std::max<int64_t>(1, (m_pad * rec_bytes + 8 * l2_seg_bytes - 1) / (8 * l2_seg_bytes));
     const int64_t target_blocks = 16384;
-    seg = (target_blocks + tile_blocks - 1) / tile_blocks;
-    seg = std::min<int64_t>(seg, std::max<int64_t>(1, m_pad / min_seg));
-    const int64_t cap = std::max<int64_t>(1, (int64_t)(2e9 / ((double)NE * n_pad * 8)));
-    seg = std::min(seg, cap);
+    const int64_t for_parallelism = (target_blocks + tile_blocks - 1) / tile_blocks;
+    if (for_parallelism > seg) seg = (for_parallelism + 7) / 8 * 8;
+    const int64_t cap_len = std::max<int64_t>(1, m_pad / min_seg);              // segment >= min_seg sources
+    const int64_t cap_mem = std::max<int64_t>(1, (int64_t)(4e9 / ((double)NE * n_pad * 8)));
+    seg = std::min(seg, std::min(cap_len, cap_mem));
     if (seg >= 8) seg = seg / 8 * 8;
   }
   seg = std::max<int64_t>(1, std::min<int64_t>(seg, 65535));
@@ -296,7 +302,7 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     const int64_t tile_blocks = n_pad / tile;
     const int64_t batch = 8;  // two ping-pong batches of 4 records
     const int64_t m_pad = round_up(std::max<int64_t>(M, 1), batch);
-    segments = choose_segments(c, tile_blocks, m_pad, NE, n_pad, 2048);
+    segments = choose_segments(c, tile_blocks, m_pad, NE, n_pad, (int64_t)R * sizeof(real), 1024);
     seg_len = round_up((m_pad + segments - 1) / segments, batch);
     segments = (int)((m_pad + seg_len - 1) / seg_len);
 
@@ -362,7 +368,7 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
       c->gen_kernel = kernel;
     }
     const int64_t tile_blocks = n_pad / BLOCK_THREADS;
-    segments = choose_segments(c, tile_blocks, M, NE, n_pad, 256);
+    segments = choose_segments(c, tile_blocks, M, NE, n_pad, (int64_t)D * sizeof(real), 256);
     seg_len = (M + segments - 1) / segments;
     segments = (int)((M + seg_len - 1) / seg_len);
     if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;

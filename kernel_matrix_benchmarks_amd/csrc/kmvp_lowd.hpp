@@ -91,14 +91,18 @@ __host__ __device__ inline real coord_scale() {
   return (real)1;
 }
 
-// blockIdx -> (tile-block, segment).  With segments % 8 == 0 every block of a
-// segment has the same blockIdx % 8 (round-robin XCD dispatch => same L2).
-__device__ __forceinline__ void block_to_work(int bid, int segments, int& tb, int& seg) {
+// blockIdx -> (tile-block, segment).  Blocks are dealt round-robin over the 8 XCDs, so
+// blockIdx % 8 labels the blocks that share an L2.  With segments % 8 == 0, XCD group g
+// only ever touches segments g, g+8, g+16, ... and works through them ONE AT A TIME
+// (the segment index varies slowest along the group's block sequence): the segment it
+// is streaming (<= ~2 MiB, see choose_segments) stays resident in its 4 MiB L2, so
+// HBM sees each source record about once per launch.  Placement only affects speed.
+__device__ __forceinline__ void block_to_work(int bid, int segments, int tile_blocks, int& tb,
+                                              int& seg) {
   if ((segments & 7) == 0) {
-    const int s8 = segments >> 3;
     const int q = bid >> 3;
-    seg = (bid & 7) + 8 * (q % s8);
-    tb = q / s8;
+    seg = (bid & 7) + 8 * (q / tile_blocks);
+    tb = q % tile_blocks;
   } else {
     seg = bid % segments;
     tb = bid / segments;
@@ -158,7 +162,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_kernel(const LowdArgs<real
   constexpr bool F32 = sizeof(real) == 4;
 
   int tb, seg;
-  block_to_work((int)blockIdx.x, a.segments, tb, seg);
+  block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // first target of this wave's tile
