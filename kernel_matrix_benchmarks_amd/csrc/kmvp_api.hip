@@ -20,6 +20,7 @@
 
 #include "../../include/kmvp.h"
 #include "kmvp_internal.hpp"
+#include "kmvp_mfma_pack.hpp"
 
 using namespace kmvp;
 
@@ -83,7 +84,8 @@ struct kmvp_ctx {
   bool have_points = false, have_signal = false, density = false;
 
   DevBuf y_raw, x_raw, b_raw;   // caller's arrays in the working precision
-  DevBuf xs, rec;               // kernel layouts (specialised path)
+  DevBuf xs, rec;               // kernel layouts (specialised path; bf16 path: augmented targets, tile images)
+  DevBuf partd;                 // bf16 path: partial denominators
   DevBuf x_scaled, y_scaled;    // scaled copies (generic path)
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
   DevBuf scratch;               // CG vectors / dot products
@@ -407,13 +409,113 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   return KMVP_OK;
 }
 
+// bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
+// to augmented bf16 rows / LDS tile images, sums come back as fp32 partials.
+int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D;
+  const int E = sig == SIG_DENSITY ? 1 : c->E;
+  const int NE = sig == SIG_NORM ? E + 1 : E;
+  const int64_t N = c->N, M = c->M;
+  const int KS = mfma_ksteps(D);
+  const int NT = (E + 31) / 32;
+  if (KS > MFMA_MAX_KS || NT > MFMA_MAX_NT)
+    return fail(c, KMVP_E_UNSUPPORTED, "bf16 MFMA path is instantiated for D <= 138 and E <= 128");
+  const int KD = 16 * KS;
+  const int NEP = NT * 32;
+  const int64_t IMG = mfma_image_bytes(KS, NT);
+  const float scale = scale_for<float>(kernel);
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int64_t tile = (int64_t)MFMA_TILE * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(N, tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t m_tiles = (M + MFMA_TILE - 1) / MFMA_TILE;
+  int rc;
+
+  // segments: enough workgroups for >= 4 per CU, at least 8 source tiles each
+  int64_t seg = c->opt_segments > 0 ? c->opt_segments : (1024 + tile_blocks - 1) / tile_blocks;
+  seg = std::max<int64_t>(1, std::min<int64_t>(seg, std::max<int64_t>(1, m_tiles / 8)));
+  if (seg >= 8) seg = seg / 8 * 8;
+  const int64_t seg_tiles = (m_tiles + seg - 1) / seg;
+  const int segments = (int)((m_tiles + seg_tiles - 1) / seg_tiles);
+
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                         c->packed_T != -2;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * KD * 2))) return rc;
+    hipLaunchKernelGGL(pack_mfma_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream,
+                       x_raw, (__bf16*)c->xs.p, N, n_pad, D, KD, scale);
+  }
+  if (sig_stale) {
+    if ((rc = ensure(c, c->rec, (size_t)m_tiles * IMG))) return rc;
+    hipLaunchKernelGGL(pack_mfma_sources_kernel, dim3(blocks_for(m_tiles * MFMA_TILE)), dim3(256), 0,
+                       c->stream, (const float*)c->y_raw.p,
+                       sig == SIG_DENSITY ? (const float*)nullptr : (const float*)c->b_raw.p,
+                       (unsigned char*)c->rec.p, M, m_tiles, D, E, KS, NT, scale);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = kernel;
+  c->packed_sig = sig;
+  c->packed_T = -2;  // marks the bf16 layouts
+
+  if ((rc = ensure(c, c->part, (size_t)segments * n_pad * NEP * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->partd, (size_t)segments * n_pad * sizeof(float)))) return rc;
+  MfmaArgs a;
+  a.xa = (const __bf16*)c->xs.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.part = (float*)c->part.p;
+  a.partd = (float*)c->partd.p;
+  a.n_pad = n_pad;
+  a.m_tiles = m_tiles;
+  a.seg_tiles = seg_tiles;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.j_offset = c->j_offset;
+  a.m_total = c->m_total;
+  const dim3 grid((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  hipError_t le;
+  switch (kernel) {
+    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_mfma_invdist(KS, NT, a, grid, c->stream, &c->last_kernel_name); break;
+  }
+  HIP_TRY(c, le);
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+  const int64_t count = (int64_t)NE * n_pad;
+  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(mfma_reduce_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                     (const float*)c->part.p, (const float*)c->partd.p, (double*)c->sums.p, n_pad, NEP,
+                     E, segments, sig == SIG_NORM ? 1 : 0);
+  HIP_TRY(c, hipGetLastError());
+  if (c->comm && c->world > 1) {
+    ncclResult_t r = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, ncclFloat64, ncclSum,
+                                      c->comm, c->stream);
+    if (r != ncclSuccess)
+      return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  }
+  if ((rc = ensure(c, c->out, (size_t)N * E * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(N)), dim3(256), 0, c->stream,
+                     (const double*)c->sums.p, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
+  c->out_n = N;
+  c->out_e = E;
+  return KMVP_OK;
+}
+
 int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   if (!c) return KMVP_E_INVALID;
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
   if (!c->have_signal) return fail(c, KMVP_E_INVALID, "kmvp_set_signal has not been called");
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->dtype == KMVP_BF16)
-    return fail(c, KMVP_E_UNSUPPORTED, "bf16 MFMA path is not built into this library yet");
   if (c->N == 0 || c->M == 0) {
     // empty clouds: a = 0 (N,E); nothing to launch
     const int E = c->density ? 1 : c->E;
@@ -444,6 +546,7 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     return KMVP_OK;
   }
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
+  if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
   if (c->dtype == KMVP_F64) return run_product_t<double>(c, kernel, sig);
   return run_product_t<float>(c, kernel, sig);
 }
@@ -676,7 +779,7 @@ void kmvp_destroy(kmvp_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled, &c->y_scaled,
-                    &c->part, &c->sums, &c->out, &c->scratch})
+                    &c->part, &c->partd, &c->sums, &c->out, &c->scratch})
     release(*b);
   for (int i = 0; i < 3; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -825,7 +928,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
   if (!c) return 0;
   size_t t = 0;
   for (const DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled,
-                          &c->y_scaled, &c->part, &c->sums, &c->out, &c->scratch})
+                          &c->y_scaled, &c->part, &c->partd, &c->sums, &c->out, &c->scratch})
     t += b->cap;
   return (int64_t)t;
 }

@@ -41,4 +41,15 @@ KMVP_DECLARE_LOWD(launch_lowd_gaussian_f64, double)
 KMVP_DECLARE_LOWD(launch_lowd_absexp_f64, double)
 KMVP_DECLARE_LOWD(launch_lowd_invdist_f64, double)
 
+// bf16 MFMA path (kmvp_mfma.hpp): largest shapes instantiated
+constexpr int MFMA_MAX_KS = 9;  // D <= 16*9 - 6 = 138
+constexpr int MFMA_MAX_NT = 4;  // E <= 128
+struct MfmaArgs;
+hipError_t launch_mfma_gaussian(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+                                const char** kernel_name);
+hipError_t launch_mfma_absexp(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+                              const char** kernel_name);
+hipError_t launch_mfma_invdist(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+                               const char** kernel_name);
+
 }  // namespace kmvp

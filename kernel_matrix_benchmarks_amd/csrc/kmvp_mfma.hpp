@@ -1,0 +1,231 @@
+// High-dimensional kernel products on the bf16 matrix cores of gfx950 (CDNA4).
+//
+//   a_i = sum_j k(x_i, y_j) b_j ,  optionally divided by sum_j k(x_i, y_j)
+//
+// Arithmetic restated from bruteforce.py:36-49 (the fast squared-distance form
+// |x|^2 + |y|^2 - 2 x.y), :18-22 / :8-15 (kernel functions) and :142-145 (numerator
+// and denominator in one sweep).  The (N,M) matrix is never formed.
+//
+// Tile algebra (one wavefront = 32 targets, one source tile = 32 sources):
+//
+//   1. squared distances straight out of the matrix pipe.  Sources and targets are
+//      stored as AUGMENTED bf16 rows of KD = 16*KS entries
+//         source j :  [ -2 y_j (D) , |y|^2 hi, mid, lo , 1 , 1 , 1 , 0.. ]
+//         target i :  [    x_i (D) ,    1   ,  1 , 1 , |x|^2 hi, mid, lo , 0.. ]
+//      so   S[j][i] = <src_j, tgt_i> = |y_j|^2 - 2 x_i.y_j + |x_i|^2   (fp32 accumulate).
+//      The norms are computed in fp32 from the bf16-rounded coordinates and split
+//      three ways (24 bits), so S is the exact squared distance of the rounded points
+//      up to fp32 accumulation error -- no VALU instruction is spent on it.
+//      KS MFMAs v_mfma_f32_32x32x16_bf16 with A = source tile (LDS), B = targets (VGPRs).
+//   2. S has the TARGET on the lane (column) and the 16 registers run over sources, so
+//      the kernel value p = k(max(S,0)) is evaluated elementwise on the VALU, the
+//      denominator is a per-lane register sum, and
+//   3. P is already the A operand of the second product  O[i][e] += sum_j P[j][i] V[j][e]
+//      (accumulator-as-operand: registers 8s..8s+7 converted pairwise to bf16 are the
+//      fragment of k-step s, with the k-order permuted: element j of lane half h is
+//      tile row 16s + 8(j>>2) + 4h + (j&3)).  The signal tile is stored TRANSPOSED in LDS
+//      ([column][source]) so that the matching B fragment is two 8-byte reads.
+//      2*NT MFMAs for NT = ceil(E/32) column tiles.
+//
+// A workgroup is 4 wavefronts = 128 targets sharing one staged source tile; tiles are
+// pre-packed by pack_mfma_sources_kernel as ready-to-copy LDS images (padded row strides:
+// conflict-free ds_read_b128 / ds_read_b64), copied with coalesced 16-byte loads,
+// double buffered, one barrier per tile.  Launch = target tile-blocks x source segments
+// as for the low-D kernels.
+//
+// Roofline: per 32x32 tile and wave, KS + 2 NT MFMAs (32 cycles each on the SIMD's
+// matrix pipe) against 16 x (1 max + transcendental(s) + 1/2 cvt + 1 add) VALU slots;
+// for exp(-r) (sqrt + exp = 8 quarter-rate slots per pair) the VALU side is the longer
+// one -- the transcendental rate, not the MFMA rate, bounds this kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmvp_lowd.hpp"  // K_*, SIG_*, WAVES_PER_BLOCK, BLOCK_THREADS, block_to_work
+
+namespace kmvp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MFMA_TILE = 32;      // sources per tile = targets per wave
+constexpr int MFMA_AUG = 6;        // augmentation columns appended to the D coordinates
+constexpr int MFMA_V_STRIDE = 72;  // bytes per transposed-signal row (32 bf16 + 8 pad)
+
+__host__ __device__ constexpr int mfma_ksteps(int D) { return (D + MFMA_AUG + 15) / 16; }
+__host__ __device__ constexpr int mfma_y_stride(int KS) { return KS * 32 + 16; }  // bytes per source row
+// bytes of one tile image, rounded up to a whole number of 16-byte pieces per thread of
+// the copying workgroup (no predication in the staging loop)
+__host__ __device__ constexpr int mfma_image_bytes(int KS, int NT) {
+  return (MFMA_TILE * mfma_y_stride(KS) + NT * 32 * MFMA_V_STRIDE + 4095) / 4096 * 4096;
+}
+
+struct MfmaArgs {
+  const __bf16* xa;          // augmented targets [n_pad][16*KS]
+  const unsigned char* img;  // source tile images [m_tiles][image_bytes]
+  float* part;               // partial numerators [segments][n_pad][NT*32]
+  float* partd;              // partial denominators [segments][n_pad]
+  int64_t n_pad;
+  int64_t m_tiles;           // source tiles in this shard
+  int64_t seg_tiles;         // tiles per segment
+  int segments;
+  int tile_blocks;
+  int64_t j_offset;
+  int64_t m_total;
+};
+
+template <int KERNEL>
+__device__ __forceinline__ float mfma_kval(float s) {
+  if constexpr (KERNEL == K_GAUSSIAN) {
+    return kexp2(-s);
+  } else if constexpr (KERNEL == K_ABSEXP) {
+    // |s| instead of max(s, 0): a free source modifier.  s < 0 only by rounding noise of the
+    // bf16/fp32 distance (~1e-6), where sqrt(|s|) ~ 1e-3 is as good an answer as 0.
+    return kexp2(-__builtin_amdgcn_sqrtf(__builtin_fabsf(s)));
+  } else {
+    return __builtin_amdgcn_rsqf(__builtin_fabsf(s));
+  }
+}
+
+// row of the 32x32 accumulator held in register `reg` by lane half `h`
+__device__ __forceinline__ constexpr int acc_row(int reg, int h) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * h;
+}
+
+template <int KERNEL, int KS, int NT>
+__global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
+  constexpr int KD = 16 * KS;
+  constexpr int YS = mfma_y_stride(KS);
+  constexpr int IMG = mfma_image_bytes(KS, NT);
+  constexpr int PIECES = IMG / (16 * BLOCK_THREADS);
+  static_assert(IMG % (16 * BLOCK_THREADS) == 0, "image is a whole number of pieces per thread");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][IMG];
+
+  int tb, seg;
+  block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int64_t i0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * MFMA_TILE;
+
+  // B operand of the distance product: this lane's target, 8 consecutive k per k-step
+  bf16x8 xb[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    xb[ks] = *reinterpret_cast<const bf16x8*>(a.xa + (i0 + r) * KD + ks * 16 + 8 * h);
+
+  // inverse-distance zero column of this lane's target (local to the shard), and the
+  // wave-uniform range of zero columns of the 32 targets (conservative when the mod wraps)
+  int64_t jz = -1, jz_lo = 0, jz_hi = -1;
+  if constexpr (KERNEL == K_INVDIST) {
+    const int64_t g = (i0 + r) % (a.m_total + 1);
+    jz = (g < a.m_total) ? g - a.j_offset : (int64_t)-1;
+    const int64_t g_lo = i0 % (a.m_total + 1);
+    const int64_t g_hi = g_lo + (MFMA_TILE - 1);
+    if (g_hi <= a.m_total) {
+      jz_lo = g_lo - a.j_offset;
+      jz_hi = g_hi - a.j_offset;
+    } else {
+      jz_lo = INT64_MIN / 2;
+      jz_hi = INT64_MAX / 2;
+    }
+  }
+
+  f32x16 o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[nt][q] = 0.f;
+  float den = 0.f;
+
+  const int64_t t_begin = (int64_t)seg * a.seg_tiles;
+  int64_t t_end = t_begin + a.seg_tiles;
+  if (t_end > a.m_tiles) t_end = a.m_tiles;
+
+  // Staging by LDS-DMA (global_load_lds_dwordx4): every wave-instruction copies 1 KiB of
+  // the tile image straight into LDS (wave-uniform LDS base + lane*16, per-lane global
+  // address), no VGPRs held across the tile.  The image of tile t+1 is requested right
+  // after the barrier that ends tile t-1 (its buffer is free then) and is waited for by
+  // the vmcnt(0) that __syncthreads() emits at the end of tile t: the global latency is
+  // covered by a whole tile of MFMA + VALU work, one barrier per tile.
+  auto stage_tile = [&](int64_t t, int buf) {
+    const unsigned char* src = a.img + t * IMG;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+      const int piece = (p * WAVES_PER_BLOCK + wave) * 1024;  // wave-uniform LDS offset
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + piece + lane * 16),
+          (__attribute__((address_space(3))) void*)(&lds[buf][piece]), 16, 0, 0);
+    }
+  };
+  if (t_begin < t_end) stage_tile(t_begin, 0);
+  __syncthreads();  // vmcnt(0) + barrier: tile t_begin and the target fragments have landed
+
+  for (int64_t t = t_begin; t < t_end; ++t) {
+    const int buf = (int)((t - t_begin) & 1);
+    if (t + 1 < t_end) stage_tile(t + 1, buf ^ 1);
+    const unsigned char* ly = &lds[buf][0];
+    const unsigned char* lv = &lds[buf][MFMA_TILE * YS];
+
+    // ---- 1. S[j][i]: KS MFMAs, A = source rows from LDS (row r of the tile)
+    f32x16 s;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s[q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 ya = *reinterpret_cast<const bf16x8*>(ly + r * YS + (ks * 16 + 8 * h) * 2);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xb[ks], s, 0, 0, 0);
+    }
+
+    // ---- 2. kernel values on the VALU; target on the lane, 16 sources in registers
+    const int64_t j0 = t * MFMA_TILE;
+    bool check = false;
+    if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
+    float p[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float k = mfma_kval<KERNEL>(s[q]);
+      if constexpr (KERNEL == K_INVDIST) {
+        if (check) k = (j0 + acc_row(q, h) == jz) ? 0.f : k;
+      }
+      p[q] = k;
+      den += k;
+    }
+
+    // ---- 3. O[i][e] += sum_j P[j][i] V[j][e]: P registers are the A operand
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pa;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pa[j] = (__bf16)p[8 * s2 + j];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned char* row = lv + (nt * 32 + r) * MFMA_V_STRIDE;
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 4 * h) * 2);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 8 + 4 * h) * 2);
+        bf16x8 vb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vb[j] = v0[j];
+          vb[4 + j] = v1[j];
+        }
+        o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, o[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: numerators [segment][target][column] (128-byte rows per register),
+  // denominators: the two lane halves hold the two halves of each target's sources
+  den += __shfl_xor(den, 32);
+  float* part = a.part + ((int64_t)seg * a.n_pad + i0) * (NT * 32);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) part[(int64_t)acc_row(q, h) * (NT * 32) + nt * 32 + r] = o[nt][q];
+  if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + r] = den;
+}
+
+}  // namespace kmvp

@@ -75,6 +75,40 @@ def test_float32_matches_reference(case, expected):
     assert extra["n_gpus"] == 1 and extra["device_kernel"]
 
 
+TOL_BF16 = 1e-2  # bf16 inputs (8-bit mantissa) with fp32 accumulation; measured 2.4e-3 .. 4e-3
+HIGH_D = [c for c in CASES if c["D"] >= 16]
+
+
+@pytest.mark.parametrize("case", HIGH_D, ids=[c["name"] for c in HIGH_D])
+def test_bfloat16_mfma_matches_reference(case, expected):
+    y, x, b = golden_cases.make_inputs(case)
+    truth = expected[f"{case['name']}/f64"]
+    got, extra = run_plugin(case, y, x, b, "bfloat16")
+    assert got.shape == truth.shape and extra["device_kernel"] == "mfma_kernel"
+    assert rel_err(got, truth) <= TOL_BF16, rel_err(got, truth)
+
+
+def test_config3_attention_65536_row_subset():
+    """BASELINE config 3: exponential-kernel attention, D = 64, E = 64, N = M = 65536, bf16 MFMA."""
+    n, D, E = 65536, 64, 64
+    rs = np.random.RandomState(n + D)
+    y = rs.rand(n, D) / np.sqrt(D)  # points scaled by 1/sqrt(D) (SURVEY 8d)
+    b = rs.randn(n, E)
+    rows = np.random.RandomState(0).choice(n, size=128, replace=False)
+    for kernel in ("absolute-exponential", "gaussian"):
+        algo = MI355XProduct(kernel=kernel, dimension=D, normalize_rows=True, precision="bfloat16")
+        try:
+            algo.prepare_data(source_points=y, target_points=y, same_points=True)
+            algo.prepare_query(source_signal=b)
+            algo.query()
+            a = algo.get_result()
+        finally:
+            algo.done()
+        want = c_oracle.product(kernel=kernel, source_points=y, source_signal=b, normalize_rows=True, rows=rows)
+        assert rel_err(a[rows], want) <= TOL_BF16
+        assert a.min() >= b.min() - 0.05 and a.max() <= b.max() + 0.05  # convex combinations
+
+
 def test_every_tuning_variant_gives_the_same_answer(expected):
     case = next(c for c in CASES if c["name"] == "gaussian-N257-M193-D3-E1")
     y, x, b = golden_cases.make_inputs(case)
