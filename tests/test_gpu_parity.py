@@ -321,3 +321,50 @@ def test_cg_solver_config5_shape_small():
     Kb = c_oracle.product(kernel="gaussian", source_points=y, source_signal=sol, rows=rows)
     assert info["cg_relative_residual"] <= 1e-6, info
     assert np.linalg.norm(Kb - a[rows]) / np.linalg.norm(a[rows]) <= 5e-6
+
+
+# ---- the harness end to end: dataset file -> registry -> runner protocol -> result files
+
+def test_runner_end_to_end_on_gpu(tmp_path):
+    from kernel_matrix_benchmarks_amd import datasets, metrics, results, runner, storage
+
+    name = "product-cube-D3-E1-M3000-N3000-inverse-distance"
+    data_root, results_root = str(tmp_path / "data"), str(tmp_path / "results")
+    stored = runner.run_dataset(name, hardware="GPU", runs=2, data_root=data_root,
+                                results_root=results_root, verbose=False)
+    assert len(stored) == 2  # float32 and float64 run-group entries of algos.yaml
+    # the generated dataset follows the reference's recipe and its truth is the oracle's answer
+    f, D = datasets.get_dataset(name, root=data_root)
+    try:
+        y = np.asarray(f["source_points"][:])
+        b = np.asarray(f["source_signal"][:])
+        truth = np.asarray(f["target_signal"][:])
+        assert D == 3 and bool(f.attrs["same_points"]) and not bool(f.attrs["density_estimation"])
+        assert f.attrs["kernel"] == "inverse-distance" and f.attrs["task"] == "product"
+    finally:
+        f.close()
+    yo, bo = kmvp_oracle.uniform_cube(3000, 3)
+    assert np.array_equal(y, yo) and np.array_equal(b, bo)
+    want = kmvp_oracle.product(kernel="inverse-distance", source_points=y, source_signal=b)
+    assert rel_err(truth, want) <= TOL64
+    for fn, attrs, result in stored:
+        assert fn.endswith(storage.extension()) and attrs["algo"] == "mi355x-product"
+        assert attrs["build_time"] < 0.05 and attrs["query_time"] > 0 and attrs["n_gpus"] == 1
+    by_name = {attrs["name"]: (fn, result) for fn, attrs, result in stored}
+    err64 = metrics.relative_max_error(by_name["MI355XProduct(float64)"][1], truth)
+    err32 = metrics.relative_max_error(by_name["MI355XProduct(float32)"][1], truth)
+    assert err64 <= TOL64 and err32 <= 2 * TOL32
+    loaded = list(results.load_all_results(name, root=results_root))
+    assert sorted(p["name"] for p, _ in loaded) == sorted(by_name)
+
+
+def test_runner_solver_dataset_on_gpu(tmp_path):
+    from kernel_matrix_benchmarks_amd import runner
+
+    name = "solver-cube-D3-E1-M400-N400-absolute-exponential"
+    stored = runner.run_dataset(name, hardware="GPU", runs=1, data_root=str(tmp_path / "data"),
+                                results_root=str(tmp_path / "results"), verbose=False)
+    assert len(stored) == 2
+    for fn, attrs, result in stored:
+        assert attrs["algo"] == "mi355x-solver" and result.shape == (400, 1)
+        assert attrs["cg_converged"] and attrs["cg_relative_residual"] <= (1e-6 if "float64" in attrs["name"] else 1e-4)
