@@ -38,7 +38,15 @@ KERNELS = {"gaussian": "gaussian", "absexp": "absolute-exponential", "invdist": 
 # per pair: flops counting fma = 2, transcendental = 1 (3D + 2E + 1 for gaussian, D=3, E=1)
 # and VALU issue slots counting a quarter-rate transcendental as 4
 FLOPS_PER_PAIR = {"gaussian": 12, "inverse-distance": 12, "absolute-exponential": 13}
-SLOTS_PER_PAIR = {"gaussian": 11, "inverse-distance": 11, "absolute-exponential": 15}
+# VALU issue slots per pair of the two pair-loop kernels: lowd_kernel (difference form: 6 for the
+# squared distance + transcendental(s) + 1 FMA) and fast_kernel (squared distance on the matrix
+# cores: only the transcendental(s) + 1 FMA stay on the VALU)
+SLOTS_PER_PAIR = {
+    "lowd_kernel": {"gaussian": 11, "inverse-distance": 11, "absolute-exponential": 15},
+    "fast_kernel": {"gaussian": 5, "inverse-distance": 5, "absolute-exponential": 9},
+}
+MFMA_FLOPS_PER_PAIR_FAST = 2 * 32  # two 32x32x16 bf16 k-steps (K = 6 D + 6 = 24 -> 32) for D = 3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 
 
 def parse():
@@ -49,6 +57,9 @@ def parse():
     p.add_argument("--n", type=float, default=1e6, help="points (N = M); default = BASELINE config 2")
     p.add_argument("--kernel", choices=sorted(KERNELS), default="gaussian")
     p.add_argument("--precision", choices=["float32", "float64"], default="float32")
+    p.add_argument("--sqdists", choices=["auto", "difference", "expanded"], default="auto",
+                   help="squared-distance form (the reference's fast_sqdists flag): auto = expanded form on "
+                        "the matrix cores where it is as accurate as the difference form")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
     return p.parse_args()
@@ -120,7 +131,9 @@ def main():
     y = rs.rand(n, D)
     b = rs.randn(n, E)
 
-    algo = MI355XProduct(kernel=kernel, dimension=D, precision=args.precision, device=local_rank, comm=comm)
+    fast = {"auto": None, "difference": False, "expanded": True}[args.sqdists]
+    algo = MI355XProduct(kernel=kernel, dimension=D, precision=args.precision, device=local_rank, comm=comm,
+                         fast_sqdists=fast)
     algo.prepare_data(source_points=y, target_points=y, same_points=True)  # H2D, untimed (runner.py:75-80)
     algo.prepare_query(source_signal=b)
     for _ in range(args.warmup):
@@ -141,6 +154,19 @@ def main():
         elapsed = float(t[0])
 
     a = algo.get_result()
+    kname = algo._ctx.last_kernel_name
+    # the other squared-distance form on the same resident data, for the record (3 steps, untimed region)
+    other = None
+    if args.sqdists == "auto" and kname == "fast_kernel" and world == 1:
+        algo._ctx.set_option("fast_sqdists", 0)
+        algo.query()
+        oms = []
+        for _ in range(3):
+            algo.query()
+            oms.append(algo._ctx.last_kernel_ms)
+        other = {"kernel": algo._ctx.last_kernel_name, "kernel_ms": float(np.mean(oms)),
+                 "pairs_per_s": float(n) * float(n) / (float(np.mean(oms)) * 1e-3)}
+        algo._ctx.set_option("fast_sqdists", -1)
     max_err = rel_err = None
     if rank == 0:
         # max |err| against the float64 oracle on a fixed sample of rows (BASELINE metric's error leg)
@@ -164,7 +190,7 @@ def main():
         # (tools/profile_bench.sh -> tools/summarize_profile.py); latest committed round wins
         import glob
 
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gaussian_1e6_f32_traffic.json")))
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_gaussian_1e6_f32_{kname}_traffic.json")))
         if tfiles and world == 1 and n == 1000000 and kernel == "gaussian" and args.precision == "float32":
             traffic = json.load(open(tfiles[-1])).get("hbm_bytes_per_launch")
         tiles = -(-n // 64)  # one 64-lane wavefront per target tile (T = 1)
@@ -191,7 +217,7 @@ def main():
             "max_rel_err": rel_err,
             "roofline": {
                 "bound": "valu",
-                "kernel": algo._ctx.last_kernel_name,
+                "kernel": kname,
                 "achieved": achieved_tflops,
                 "peak": PEAK_FP32_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
@@ -201,8 +227,11 @@ def main():
                 "step_device_ms": total_ms,
                 "flops_per_pair": FLOPS_PER_PAIR[kernel],
                 # the same launch priced in VALU issue slots (transcendental = 4 slots)
-                "issue_slots_per_pair": SLOTS_PER_PAIR[kernel],
-                "issue_frac": SLOTS_PER_PAIR[kernel] * shard_pairs / (k_ms * 1e-3) / PEAK_ISSUE_SLOTS,
+                "issue_slots_per_pair": SLOTS_PER_PAIR.get(kname, SLOTS_PER_PAIR["lowd_kernel"])[kernel],
+                "issue_frac": SLOTS_PER_PAIR.get(kname, SLOTS_PER_PAIR["lowd_kernel"])[kernel] * shard_pairs
+                              / (k_ms * 1e-3) / PEAK_ISSUE_SLOTS,
+                "mfma_frac": (MFMA_FLOPS_PER_PAIR_FAST * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
+                              if kname == "fast_kernel" else 0.0),
                 # north-star's "HBM" reading: bytes every wavefront streams from the source block
                 "source_stream_GBps": tiles * float(algo._shard[1] - algo._shard[0]) * (D + E) * 4 / (k_ms * 1e-3) / 1e9,
                 "source_stream_frac_of_hbm_peak": tiles * float(algo._shard[1] - algo._shard[0]) * (D + E) * 4
@@ -210,6 +239,11 @@ def main():
                 "algorithmic_hbm_bytes": 4 * (n * D + (algo._shard[1] - algo._shard[0]) * (D + E) + n * E),
             },
         }
+        out["config"]["sqdists"] = ("expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "
+                                    "(reference fast_sqdists=True form)" if kname == "fast_kernel"
+                                    else "difference form (reference fast_sqdists=False)")
+        if other is not None:
+            out["difference_form"] = other
         if not args.no_cpu_baseline and args.gpus == 1:
             out["cpu_baseline"] = cpu_baseline(kernel, y, b, args.precision, args.cpu_seconds)
         print(json.dumps(out), flush=True)

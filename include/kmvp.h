@@ -128,7 +128,13 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  *   "feed"             -1 = auto (default), 0 = scalar-cache source stream, 1 = LDS-staged tiles
  *   "targets_per_lane" 0 = auto (default), 1, 2, 4 or 8
  *   "segments"         number of source segments a launch is split into (0 = auto)
- *   "chunk"            sources summed in fp32 before folding into the fp64 sum */
+ *   "chunk"            sources summed in fp32 before folding into the fp64 sum
+ *   "fast_sqdists"     squared distances in the expanded form |x|^2+|y|^2-2x.y on the matrix
+ *                      cores (bruteforce.py:36-49 `fast_sqdists`; float32, D <= 7, E == 1):
+ *                      1 = always, 0 = never (difference form, bruteforce.py:53-54),
+ *                      -1 = auto (default): only where it is as accurate as the difference
+ *                      form -- the Gaussian kernel on clouds of small scaled radius
+ *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4 */
 int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);
 
 /* BaseAlgorithm.get_memory_usage / get_additional (base.py:35-46): bytes of device

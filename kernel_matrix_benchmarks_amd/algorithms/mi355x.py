@@ -38,7 +38,8 @@ class MI355XProduct(BaseProduct):
     sharded over ranks (``comm`` = a ``sharding.Communicator``)."""
 
     def __init__(self, *, kernel, dimension, normalize_rows=False, precision=np.float32,
-                 device=0, comm=None, targets_per_lane=0, feed=None, segments=0, chunk=0):
+                 fast_sqdists=None, device=0, comm=None, targets_per_lane=0, feed=None, segments=0,
+                 chunk=0, fast_tiles=0):
         super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows,
                          precision=precision)
         if kernel not in SUPPORTED_KERNELS:
@@ -47,11 +48,16 @@ class MI355XProduct(BaseProduct):
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)  # NotImplementedError if unknown
         self.device = device
         self.comm = comm
+        # fast_sqdists mirrors the reference's flag (bruteforce.py:70,36-49): True = expanded
+        # |x|^2+|y|^2-2x.y form (here on the matrix cores), False = difference form; None lets
+        # the library use the expanded form only where it is equally accurate.
+        self.fast_sqdists = fast_sqdists
         self._options = dict(targets_per_lane=targets_per_lane, feed=feed, segments=segments,
-                             chunk=chunk)
+                             chunk=chunk, fast_tiles=fast_tiles)
         self._ctx = None
         self.res = None
-        self.name = f"MI355XProduct({_precision_name(precision)})"
+        self.name = f"MI355XProduct({_precision_name(precision)})" if fast_sqdists is None else (
+            f"MI355XProduct({_precision_name(precision)}, fast_sqdists={bool(fast_sqdists)})")
 
     # -- untimed -------------------------------------------------------------------
     def prepare_data(self, *, source_points, target_points, same_points=False,
@@ -72,6 +78,8 @@ class MI355XProduct(BaseProduct):
             for key, value in self._options.items():
                 if value:
                     self._ctx.set_option(key, value)
+            if self.fast_sqdists is not None:
+                self._ctx.set_option("fast_sqdists", 1 if self.fast_sqdists else 0)
         world = 1 if self.comm is None else self.comm.world
         if world > 1:
             # every rank keeps all targets and one contiguous slice of the sources

@@ -21,6 +21,7 @@
 #include "../../include/kmvp.h"
 #include "kmvp_internal.hpp"
 #include "kmvp_mfma_pack.hpp"
+#include "kmvp_fast_pack.hpp"
 
 using namespace kmvp;
 
@@ -86,6 +87,7 @@ struct kmvp_ctx {
   DevBuf y_raw, x_raw, b_raw;   // caller's arrays in the working precision
   DevBuf xs, rec;               // kernel layouts (specialised path; bf16 path: augmented targets, tile images)
   DevBuf partd;                 // bf16 path: partial denominators
+  DevBuf aux;                   // fast path: |x'|^2 per target + cloud centre
   DevBuf x_scaled, y_scaled;    // scaled copies (generic path)
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
   DevBuf scratch;               // CG vectors / dot products
@@ -100,6 +102,9 @@ struct kmvp_ctx {
 
   // tuning (kmvp_set_option)
   int opt_feed = -1, opt_T = 0, opt_segments = 0, opt_chunk = 512;
+  int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always
+  float cloud_radius2 = INFINITY;          // squared half-diagonal of the clouds' bounding box
+  uint64_t centre_ver = 0;
 
   // sharding
   ncclComm_t comm = nullptr;
@@ -409,6 +414,102 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   return KMVP_OK;
 }
 
+// split-bf16 MFMA low-D path (kmvp_fast.hpp): float32, D <= 7, E == 1, selected by the
+// "fast_sqdists" option (the reference's constructor flag of the same name).
+int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D;
+  const int E = 1;
+  const int NE = sig == SIG_NORM ? 2 : 1;
+  const int EB = sig == SIG_DENSITY ? 0 : 1;
+  const int64_t N = c->N, M = c->M;
+  const int KS = fast_ksteps(D);
+  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : FAST_DEFAULT_TT;
+  const int64_t SB = fast_stage_bytes(KS, EB);
+  const float scale = scale_for<float>(kernel);
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int64_t tile = (int64_t)FAST_TILE * TT * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(N, tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t m_tiles = (M + FAST_TILE - 1) / FAST_TILE;
+  const int64_t m_stages = (m_tiles + FAST_STAGE - 1) / FAST_STAGE;
+  int rc;
+
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, SB, 4);
+  const int64_t seg_stages = (m_stages + segments - 1) / segments;
+  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                         c->packed_T != -3 - TT;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  float* centre = (float*)c->aux.p;  // written by kmvp_set_points
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * KS * 16 * 2))) return rc;
+    hipLaunchKernelGGL(pack_fast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
+                       centre, (__bf16*)c->xs.p, N, n_pad, D, KS, scale);
+  }
+  if (sig_stale) {
+    if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
+    hipLaunchKernelGGL(pack_fast_sources_kernel, dim3(blocks_for(m_stages * FAST_STAGE * FAST_TILE)),
+                       dim3(256), 0, c->stream, (const float*)c->y_raw.p, (const float*)c->b_raw.p, centre,
+                       (unsigned char*)c->rec.p, M, m_stages, D, EB, KS, scale);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = kernel;
+  c->packed_sig = sig;
+  c->packed_T = -3 - TT;  // marks the fast-path layouts
+
+  if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
+  FastArgs a;
+  a.xa = (const __bf16*)c->xs.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.part = (double*)c->part.p;
+  a.n_pad = n_pad;
+  a.m_tiles = m_tiles;
+  a.m_stages = m_stages;
+  a.seg_stages = seg_stages;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.chunk_stages = std::max(1, c->opt_chunk / (FAST_TILE * FAST_STAGE));
+  a.j_offset = c->j_offset;
+  a.m_total = c->m_total;
+  const dim3 grid((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  hipError_t le;
+  switch (kernel) {
+    case K_GAUSSIAN: le = launch_fast_gaussian(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_fast_absexp(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_fast_invdist(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+  }
+  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
+  HIP_TRY(c, le);
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+  const int64_t count = (int64_t)NE * n_pad;
+  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->sums.p, count, segments);
+  HIP_TRY(c, hipGetLastError());
+  if (c->comm && c->world > 1) {
+    ncclResult_t r = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, ncclFloat64, ncclSum,
+                                      c->comm, c->stream);
+    if (r != ncclSuccess)
+      return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  }
+  if ((rc = ensure(c, c->out, (size_t)N * E * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(N)), dim3(256), 0, c->stream,
+                     (const double*)c->sums.p, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
+  c->out_n = N;
+  c->out_e = E;
+  return KMVP_OK;
+}
+
 // bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
 // to augmented bf16 rows / LDS tile images, sums come back as fp32 partials.
 int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
@@ -547,6 +648,16 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   }
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
+  if (c->dtype == KMVP_F32 && c->D <= FAST_MAX_D && (c->density || c->E == 1) && c->centre_ver == c->points_ver) {
+    // "fast_sqdists": expanded squared distances on the matrix cores.  auto = only where the
+    // expansion is as accurate as the difference form to working precision: the Gaussian
+    // (smooth in s; exp(-sqrt(s)) and 1/sqrt(s) amplify the absolute error of s near
+    // coincident points, as they do in the reference's own fast form) on clouds whose scaled
+    // radius keeps eps32 * (|x'|^2 + |y'|^2) ~ 1e-6.
+    const float sc = scale_for<float>(kernel);
+    const bool accurate = kernel == K_GAUSSIAN && c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
+    if (c->opt_fast == 1 || (c->opt_fast < 0 && accurate)) return run_product_fast(c, kernel, sig);
+  }
   if (c->dtype == KMVP_F64) return run_product_t<double>(c, kernel, sig);
   return run_product_t<float>(c, kernel, sig);
 }
@@ -779,7 +890,7 @@ void kmvp_destroy(kmvp_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled, &c->y_scaled,
-                    &c->part, &c->partd, &c->sums, &c->out, &c->scratch})
+                    &c->part, &c->partd, &c->aux, &c->sums, &c->out, &c->scratch})
     release(*b);
   for (int i = 0; i < 3; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -808,6 +919,17 @@ int kmvp_set_points(kmvp_ctx* c, const void* y, int64_t M, const void* x_or_null
   if (!c->same_points) {
     if ((rc = ensure(c, c->x_raw, (size_t)N * D * es))) return rc;
     if (N > 0) HIP_TRY(c, hipMemcpyAsync(c->x_raw.p, x_or_null, (size_t)N * D * es, hipMemcpyHostToDevice, c->stream));
+  }
+  c->cloud_radius2 = INFINITY;
+  if (dtype == KMVP_F32 && D <= FAST_MAX_D && M > 0 && N > 0) {
+    // bounding box of the clouds for the split-bf16 path (centre + squared half-diagonal)
+    if ((rc = ensure(c, c->aux, 16 * sizeof(float)))) return rc;
+    hipLaunchKernelGGL(fast_center_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)c->y_raw.p, M,
+                       c->same_points ? (const float*)nullptr : (const float*)c->x_raw.p, N, D,
+                       (float*)c->aux.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&c->cloud_radius2, (float*)c->aux.p + 8, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    c->centre_ver = c->points_ver + 1;
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffers are only read during the call
   c->dtype = dtype;
@@ -915,6 +1037,13 @@ int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
   } else if (k == "segments") {
     if (value < 0 || value > 65535) return fail(c, KMVP_E_INVALID, "segments out of range");
     c->opt_segments = (int)value;
+  } else if (k == "fast_sqdists") {
+    if (value < -1 || value > 1) return fail(c, KMVP_E_INVALID, "fast_sqdists must be -1 (auto), 0 or 1");
+    c->opt_fast = (int)value;
+  } else if (k == "fast_tiles") {
+    if (value != 0 && value != 1 && value != 2 && value != 4)
+      return fail(c, KMVP_E_INVALID, "fast_tiles must be 0 (auto), 1, 2 or 4");
+    c->opt_fast_tiles = (int)value;
   } else if (k == "chunk") {
     if (value < 8 || value > (1 << 24)) return fail(c, KMVP_E_INVALID, "chunk out of range");
     c->opt_chunk = (int)value;
@@ -928,7 +1057,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
   if (!c) return 0;
   size_t t = 0;
   for (const DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled,
-                          &c->y_scaled, &c->part, &c->partd, &c->sums, &c->out, &c->scratch})
+                          &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sums, &c->out, &c->scratch})
     t += b->cap;
   return (int64_t)t;
 }

@@ -1,0 +1,138 @@
+// Packing kernels of the split-bf16 MFMA low-D path (non-template kernels: included by
+// kmvp_api.hip only).  Layouts are documented in kmvp_fast.hpp.
+#pragma once
+#include "kmvp_fast.hpp"
+
+namespace kmvp {
+
+// centre[d] = midpoint of the bounding box of both clouds, centre[8] = squared half-diagonal
+// of that box (one workgroup; runs once per kmvp_set_points).  Subtracting the centre before
+// the |x|^2 + |y|^2 - 2x.y expansion keeps the cancellation error of the fast form as small
+// as the data allow; the half-diagonal bounds |x'|^2, |y'|^2 and drives the "auto" choice.
+__global__ void fast_center_kernel(const float* __restrict__ y, int64_t m, const float* __restrict__ x,
+                                   int64_t n, int D, float* __restrict__ centre) {
+  __shared__ float lo[1024], hi[1024];
+  float radius2 = 0.f;
+  for (int d = 0; d < D; ++d) {
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
+      const float v = y[i * D + d];
+      vmin = fminf(vmin, v);
+      vmax = fmaxf(vmax, v);
+    }
+    if (x != nullptr)
+      for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = x[i * D + d];
+        vmin = fminf(vmin, v);
+        vmax = fmaxf(vmax, v);
+      }
+    lo[threadIdx.x] = vmin;
+    hi[threadIdx.x] = vmax;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        lo[threadIdx.x] = fminf(lo[threadIdx.x], lo[threadIdx.x + s]);
+        hi[threadIdx.x] = fmaxf(hi[threadIdx.x], hi[threadIdx.x + s]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float c = 0.5f * (lo[0] + hi[0]);
+      const bool ok = (c == c && fabsf(c) != INFINITY);
+      centre[d] = ok ? c : 0.f;
+      const float half = ok ? 0.5f * (hi[0] - lo[0]) : INFINITY;
+      radius2 += half * half;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) centre[8] = radius2;
+}
+
+// exact three-way bf16 split of an fp32 value: v == hi + mid + lo
+__device__ __forceinline__ void fast_split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)v;
+  const float r1 = v - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}
+
+// target operands [tile][KS][32][16]: per d (x_h, x_m, x_h, x_l, x_m, x_h), then 1,1,1, |x'|^2 h,m,l
+__global__ void pack_fast_targets_kernel(const float* __restrict__ x, const float* __restrict__ centre,
+                                         __bf16* __restrict__ xa, int64_t n, int64_t n_pad, int D,
+                                         int KS, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  const int64_t tile = i / FAST_TILE;
+  const int r = (int)(i % FAST_TILE);
+  auto put = [&](int k, __bf16 v) { xa[((tile * KS + k / 16) * 32 + r) * 16 + (k % 16)] = v; };
+  const __bf16 zero = (__bf16)0.f, one = (__bf16)1.f;
+  if (i >= n) {
+    for (int k = 0; k < 16 * KS; ++k) put(k, zero);
+    return;
+  }
+  double sq = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const float v = (x[i * D + d] - centre[d]) * scale;
+    sq += (double)v * (double)v;
+    __bf16 vh, vm, vl;
+    fast_split3(v, vh, vm, vl);
+    put(6 * d + 0, vh);
+    put(6 * d + 1, vm);
+    put(6 * d + 2, vh);
+    put(6 * d + 3, vl);
+    put(6 * d + 4, vm);
+    put(6 * d + 5, vh);
+  }
+  __bf16 sh, sm, sl;
+  fast_split3((float)sq, sh, sm, sl);
+  put(6 * D + 0, one);
+  put(6 * D + 1, one);
+  put(6 * D + 2, one);
+  put(6 * D + 3, sh);
+  put(6 * D + 4, sm);
+  put(6 * D + 5, sl);
+  for (int k = 6 * D + 6; k < 16 * KS; ++k) put(k, zero);
+}
+
+// source stages: per tile [32 rows x row_bytes] (per d (-2y_h, -2y_h, -2y_m, -2y_h, -2y_m, -2y_l),
+// then |y'|^2 h,m,l, 1,1,1) followed by [32] signal floats; pad sources: |y'|^2 = +inf, b = 0.
+__global__ void pack_fast_sources_kernel(const float* __restrict__ y, const float* __restrict__ b,
+                                         const float* __restrict__ centre, unsigned char* __restrict__ img,
+                                         int64_t m, int64_t m_stages, int D, int EB, int KS, float scale) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m_stages * FAST_STAGE * FAST_TILE) return;
+  const int64_t stage = j / (FAST_STAGE * FAST_TILE);
+  const int q = (int)((j / FAST_TILE) % FAST_STAGE);
+  const int r = (int)(j % FAST_TILE);
+  const int RB = fast_row_bytes(KS);
+  unsigned char* tile = img + stage * (int64_t)fast_stage_bytes(KS, EB) + q * fast_tile_bytes(KS, EB);
+  __bf16* row = reinterpret_cast<__bf16*>(tile + r * RB);
+  const bool live = j < m;
+  const __bf16 zero = (__bf16)0.f, one = (__bf16)1.f;
+  double sq = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const float v = live ? (y[j * D + d] - centre[d]) * scale : 0.f;
+    sq += (double)v * (double)v;
+    __bf16 vh, vm, vl;
+    fast_split3(v, vh, vm, vl);
+    const __bf16 h2 = (__bf16)(-2.f * (float)vh), m2 = (__bf16)(-2.f * (float)vm), l2 = (__bf16)(-2.f * (float)vl);
+    row[6 * d + 0] = h2;
+    row[6 * d + 1] = h2;
+    row[6 * d + 2] = m2;
+    row[6 * d + 3] = h2;
+    row[6 * d + 4] = m2;
+    row[6 * d + 5] = l2;
+  }
+  __bf16 sh, sm, sl;
+  fast_split3((float)sq, sh, sm, sl);
+  row[6 * D + 0] = live ? sh : (__bf16)INFINITY;
+  row[6 * D + 1] = live ? sm : zero;
+  row[6 * D + 2] = live ? sl : zero;
+  row[6 * D + 3] = one;
+  row[6 * D + 4] = one;
+  row[6 * D + 5] = one;
+  for (int k = 6 * D + 6; k < 16 * KS + 8; ++k) row[k] = zero;  // incl. the 16-byte row pad
+  if (EB > 0) reinterpret_cast<float*>(tile + FAST_TILE * RB)[r] = live ? b[j] : 0.f;
+}
+
+}  // namespace kmvp

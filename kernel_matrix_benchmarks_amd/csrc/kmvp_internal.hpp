@@ -52,4 +52,18 @@ hipError_t launch_mfma_absexp(int KS, int NT, const MfmaArgs& args, dim3 grid, h
 hipError_t launch_mfma_invdist(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
                                const char** kernel_name);
 
+
+// split-bf16 MFMA low-D path (kmvp_fast.hpp): 6 D + 6 <= 48, E == 1
+constexpr int FAST_MAX_D = 7;
+constexpr int FAST_DEFAULT_TT = 4;
+// auto mode: scaled squared radius of the clouds below which the expansion is used
+constexpr float FAST_AUTO_RADIUS2 = 8.0f;
+struct FastArgs;
+hipError_t launch_fast_gaussian(int KS, int sig, int TT, const FastArgs& args, dim3 grid,
+                                hipStream_t stream, const char** kernel_name);
+hipError_t launch_fast_absexp(int KS, int sig, int TT, const FastArgs& args, dim3 grid,
+                              hipStream_t stream, const char** kernel_name);
+hipError_t launch_fast_invdist(int KS, int sig, int TT, const FastArgs& args, dim3 grid,
+                               hipStream_t stream, const char** kernel_name);
+
 }  // namespace kmvp

@@ -75,6 +75,52 @@ def test_float32_matches_reference(case, expected):
     assert extra["n_gpus"] == 1 and extra["device_kernel"]
 
 
+LOW_D_E1 = [c for c in CASES if c["D"] <= 7 and (c["E"] == 1 or c["density_estimation"])]
+
+
+@pytest.mark.parametrize("case", LOW_D_E1, ids=[c["name"] for c in LOW_D_E1])
+def test_fast_sqdists_matches_reference(case, expected):
+    """fast_sqdists=True: expanded squared distances on the matrix cores (split-bf16 MFMA).
+    Same tolerance as the difference form for the Gaussian; for exp(-r) and 1/r the error of
+    the expansion near coincident points is inherent (the reference's own fast form has it
+    too), so the bound there is twice the error of the REFERENCE's float32 fast run."""
+    y, x, b = golden_cases.make_inputs(case)
+    truth = expected[f"{case['name']}/f64"]
+    if not np.isfinite(truth).all():
+        pytest.skip("coincident points: the expansion has no exact zero distance")
+    got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists=True)
+    if not (case["normalize_rows"] and case["density_estimation"]):
+        assert extra["device_kernel"] == "fast_kernel"
+    if case["kernel"] == "gaussian":
+        tol = TOL32
+    else:
+        # not smooth at s = 0: the absolute error of the expanded s is amplified near coincident
+        # points -- in the reference's fast form as well, which calibrates the bound
+        ref32fast = expected[f"{case['name']}/f32fast"].astype(np.float64)
+        fin = np.isfinite(ref32fast).all(axis=-1)
+        floor = 1e-3 if case["kernel"] == "inverse-distance" else 1e-4
+        tol = max(floor, 2 * rel_err(ref32fast[fin], truth[fin]))
+    assert rel_err(got, truth) <= tol, (rel_err(got, truth), tol)
+
+
+def test_fast_sqdists_auto_policy():
+    """auto: unit-cube gaussian -> matrix cores; same cloud blown up 100x, or 1/r -> difference form."""
+    y, b = kmvp_oracle.uniform_cube(2000, 3)
+    _, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32")
+    assert extra["device_kernel"] == "fast_kernel"
+    _, extra = run_plugin(dict(kernel="gaussian", D=3), 100 * y + 1e4, None, b, "float32")
+    assert extra["device_kernel"] == "lowd_kernel"
+    _, extra = run_plugin(dict(kernel="inverse-distance", D=3), y, None, b, "float32")
+    assert extra["device_kernel"] == "lowd_kernel"
+    _, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32", fast_sqdists=False)
+    assert extra["device_kernel"] == "lowd_kernel"
+    got, extra = run_plugin(dict(kernel="gaussian", D=3), y + 1e3, None, b, "float32")  # far from the origin
+    assert extra["device_kernel"] == "fast_kernel"  # centring makes the offset harmless
+    want = kmvp_oracle.product(kernel="gaussian", source_points=(y + 1e3).astype(np.float32).astype(np.float64),
+                               source_signal=b)
+    assert rel_err(got, want) <= TOL32
+
+
 TOL_BF16 = 1e-2  # bf16 inputs (8-bit mantissa) with fp32 accumulation; measured 2.4e-3 .. 4e-3
 HIGH_D = [c for c in CASES if c["D"] >= 16]
 
@@ -120,10 +166,14 @@ def test_every_tuning_variant_gives_the_same_answer(expected):
             for T in (1, 2, 4, 8):
                 for seg in (0, 1, 3, 8):
                     got, _ = run_plugin(c, y, x, b, np.float32, feed=feed if feed else None,
-                                        targets_per_lane=T, segments=seg)
+                                        targets_per_lane=T, segments=seg, fast_sqdists=False)
                     assert rel_err(got, want) <= TOL32, (kernel, feed, T, seg, rel_err(got, want))
-        got, _ = run_plugin(c, y, x, b, np.float32, chunk=8)
+        got, _ = run_plugin(c, y, x, b, np.float32, chunk=8, fast_sqdists=False)
         assert rel_err(got, want) <= TOL32
+        if kernel == "gaussian":
+            for tiles in (1, 2, 4):
+                got, _ = run_plugin(c, y, x, b, np.float32, fast_sqdists=True, fast_tiles=tiles, segments=3)
+                assert rel_err(got, want) <= TOL32
 
 
 def test_results_are_bitwise_reproducible():
