@@ -38,7 +38,9 @@ for k in sorted(per_kernel):
         mean = sum(vals) / len(vals)
         lines.append(f"| `{k[-60:]}` | {c} | {mean:,.1f} |")
         summary.setdefault(k, {})[c] = mean
-main = next((k for k in summary if "lowd_kernel" in k or "mfma" in k), None)
+bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+want = bench.get("roofline", {}).get("kernel", "lowd_kernel")
+main = next((k for k in summary if want in k), None)
 if main and "FETCH_SIZE" in summary[main]:
     fetch = summary[main]["FETCH_SIZE"] * 1024 * 2   # gfx950 correction for 16 B/lane streams
     # 8-byte-per-lane stores are outside the guide's calibrated range for WRITE_SIZE (it reads
