@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>  // types only: the library is dlopen'ed on first use
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -43,13 +44,34 @@ struct Rccl {
                             hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  std::string error;
+  std::string error, path;
   bool load() {
     if (handle) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-      handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-      if (handle) break;
+    // RCCL must drive the SAME HIP runtime as this library: a process may hold two ROCm
+    // stacks (e.g. the system one and the copy bundled with PyTorch), and a bare
+    // dlopen("librccl.so.1") returns whichever copy happens to be loaded already.  So look
+    // next to the libamdhip64 this library is bound to first, by absolute path.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+      char resolved[4096];
+      std::string hip_path = realpath(info.dli_fname, resolved) ? resolved : info.dli_fname;
+      const size_t slash = hip_path.rfind('/');
+      if (slash != std::string::npos) {
+        const std::string dir = hip_path.substr(0, slash + 1);
+        names.push_back(dir + "librccl.so.1");
+        names.push_back(dir + "librccl.so");
+      }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& n : names) {
+      handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (handle) {
+        path = n;
+        break;
+      }
     }
     if (!handle) {
       error = std::string("cannot load librccl: ") + dlerror();

@@ -418,3 +418,17 @@ def test_runner_solver_dataset_on_gpu(tmp_path):
     for fn, attrs, result in stored:
         assert attrs["algo"] == "mi355x-solver" and result.shape == (400, 1)
         assert attrs["cg_converged"] and attrs["cg_relative_residual"] <= (1e-6 if "float64" in attrs["name"] else 1e-4)
+
+
+def test_rccl_binds_to_the_hip_runtime_in_use():
+    """A process can hold two ROCm stacks (system + the copy bundled with PyTorch).  libkmvp.so
+    must dlopen the RCCL that belongs to the HIP runtime it is itself bound to, in both import
+    orders; bench.py uses the libkmvp-first order (tools/rccl_stack_check.py)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_stack_check.py")], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert "kmvp_first exit 0" in out.stdout and "torch_first exit 0" in out.stdout, out.stdout + out.stderr
