@@ -54,13 +54,15 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--n", type=float, default=1e6, help="points (N = M); default = BASELINE config 2")
+    p.add_argument("--points", dest="n", type=float, default=1e6, help="points (N = M); default = BASELINE config 2")
     p.add_argument("--kernel", choices=sorted(KERNELS), default="gaussian")
     p.add_argument("--precision", choices=["float32", "float64"], default="float32")
     p.add_argument("--sqdists", choices=["auto", "difference", "expanded"], default="auto",
                    help="squared-distance form (the reference's fast_sqdists flag): auto = expanded form on "
                         "the matrix cores where it is as accurate as the difference form")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--all-ranks-on-device", type=int, default=None,
+                   help="debug: put every rank on this one GPU (rehearses the multi-rank path on a 1-GPU box)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
     return p.parse_args()
 
@@ -132,7 +134,8 @@ def main():
     b = rs.randn(n, E)
 
     fast = {"auto": None, "difference": False, "expanded": True}[args.sqdists]
-    algo = MI355XProduct(kernel=kernel, dimension=D, precision=args.precision, device=local_rank, comm=comm,
+    device = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
+    algo = MI355XProduct(kernel=kernel, dimension=D, precision=args.precision, device=device, comm=comm,
                          fast_sqdists=fast)
     algo.prepare_data(source_points=y, target_points=y, same_points=True)  # H2D, untimed (runner.py:75-80)
     algo.prepare_query(source_signal=b)
