@@ -548,7 +548,8 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   const int64_t IMG = mfma_image_bytes(KS, NT);
   const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
-  const int64_t tile = (int64_t)MFMA_TILE * WAVES_PER_BLOCK;
+  const int TW = c->opt_T == 1 ? 1 : 2;  // target tiles of 32 per wave ("targets_per_lane" option: 1 or 2)
+  const int64_t tile = (int64_t)MFMA_TILE * TW * WAVES_PER_BLOCK;
   const int64_t n_pad = round_up(N, tile);
   const int64_t tile_blocks = n_pad / tile;
   const int64_t m_tiles = (M + MFMA_TILE - 1) / MFMA_TILE;
@@ -562,7 +563,7 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   const int segments = (int)((m_tiles + seg_tiles - 1) / seg_tiles);
 
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
-                         c->packed_T != -2;
+                         c->packed_T != -2 - 100 * TW;
   const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (pts_stale) {
@@ -582,7 +583,7 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   c->packed_signal_ver = c->signal_ver;
   c->packed_kernel = kernel;
   c->packed_sig = sig;
-  c->packed_T = -2;  // marks the bf16 layouts
+  c->packed_T = -2 - 100 * TW;  // marks the bf16 layouts
 
   if ((rc = ensure(c, c->part, (size_t)segments * n_pad * NEP * sizeof(float)))) return rc;
   if ((rc = ensure(c, c->partd, (size_t)segments * n_pad * sizeof(float)))) return rc;
@@ -602,9 +603,9 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   hipError_t le;
   switch (kernel) {
-    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, a, grid, c->stream, &c->last_kernel_name); break;
-    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, a, grid, c->stream, &c->last_kernel_name); break;
-    default: le = launch_mfma_invdist(KS, NT, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_mfma_invdist(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
   }
   HIP_TRY(c, le);
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));

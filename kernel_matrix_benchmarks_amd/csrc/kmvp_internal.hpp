@@ -45,11 +45,11 @@ KMVP_DECLARE_LOWD(launch_lowd_invdist_f64, double)
 constexpr int MFMA_MAX_KS = 9;  // D <= 16*9 - 6 = 138
 constexpr int MFMA_MAX_NT = 4;  // E <= 128
 struct MfmaArgs;
-hipError_t launch_mfma_gaussian(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+hipError_t launch_mfma_gaussian(int KS, int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream,
                                 const char** kernel_name);
-hipError_t launch_mfma_absexp(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+hipError_t launch_mfma_absexp(int KS, int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream,
                               const char** kernel_name);
-hipError_t launch_mfma_invdist(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+hipError_t launch_mfma_invdist(int KS, int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream,
                                const char** kernel_name);
 
 

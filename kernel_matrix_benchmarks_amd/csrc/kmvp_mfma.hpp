@@ -93,7 +93,7 @@ __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * h;
 }
 
-template <int KERNEL, int KS, int NT>
+template <int KERNEL, int KS, int NT, int TW>
 __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
   constexpr int KD = 16 * KS;
   constexpr int YS = mfma_y_stride(KS);
@@ -108,22 +108,30 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31;
   const int h = lane >> 5;
-  const int64_t i0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * MFMA_TILE;
+  // a wave owns TW target tiles of 32; the source fragments it reads from LDS serve all of them
+  const int64_t i0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * (MFMA_TILE * TW);
 
-  // B operand of the distance product: this lane's target, 8 consecutive k per k-step
-  bf16x8 xb[KS];
+  // B operand of the distance product: this lane's targets, 8 consecutive k per k-step
+  bf16x8 xb[TW][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-    xb[ks] = *reinterpret_cast<const bf16x8*>(a.xa + (i0 + r) * KD + ks * 16 + 8 * h);
+  for (int w = 0; w < TW; ++w)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      xb[w][ks] = *reinterpret_cast<const bf16x8*>(a.xa + (i0 + w * MFMA_TILE + r) * KD + ks * 16 + 8 * h);
 
-  // inverse-distance zero column of this lane's target (local to the shard), and the
-  // wave-uniform range of zero columns of the 32 targets (conservative when the mod wraps)
-  int64_t jz = -1, jz_lo = 0, jz_hi = -1;
+  // inverse-distance zero column of this lane's targets (local to the shard), and the
+  // wave-uniform range of zero columns of the wave's targets (conservative when the mod wraps)
+  int64_t jz[TW], jz_lo = 0, jz_hi = -1;
+#pragma unroll
+  for (int w = 0; w < TW; ++w) jz[w] = -1;
   if constexpr (KERNEL == K_INVDIST) {
-    const int64_t g = (i0 + r) % (a.m_total + 1);
-    jz = (g < a.m_total) ? g - a.j_offset : (int64_t)-1;
+#pragma unroll
+    for (int w = 0; w < TW; ++w) {
+      const int64_t g = (i0 + w * MFMA_TILE + r) % (a.m_total + 1);
+      jz[w] = (g < a.m_total) ? g - a.j_offset : (int64_t)-1;
+    }
     const int64_t g_lo = i0 % (a.m_total + 1);
-    const int64_t g_hi = g_lo + (MFMA_TILE - 1);
+    const int64_t g_hi = g_lo + (MFMA_TILE * TW - 1);
     if (g_hi <= a.m_total) {
       jz_lo = g_lo - a.j_offset;
       jz_hi = g_hi - a.j_offset;
@@ -133,12 +141,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
     }
   }
 
-  f32x16 o[NT];
+  f32x16 o[TW][NT];
+  float den[TW];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int w = 0; w < TW; ++w) {
+    den[w] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) o[nt][q] = 0.f;
-  float den = 0.f;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[w][nt][q] = 0.f;
+  }
 
   const int64_t t_begin = (int64_t)seg * a.seg_tiles;
   int64_t t_end = t_begin + a.seg_tiles;
@@ -169,49 +181,59 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
     const unsigned char* ly = &lds[buf][0];
     const unsigned char* lv = &lds[buf][MFMA_TILE * YS];
 
-    // ---- 1. S[j][i]: KS MFMAs, A = source rows from LDS (row r of the tile)
-    f32x16 s;
+    // source fragments of the tile, read once for all TW target tiles
+    bf16x8 ya[KS];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s[q] = 0.f;
+    for (int ks = 0; ks < KS; ++ks)
+      ya[ks] = *reinterpret_cast<const bf16x8*>(ly + r * YS + (ks * 16 + 8 * h) * 2);
+    bf16x8 vb[2][NT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 ya = *reinterpret_cast<const bf16x8*>(ly + r * YS + (ks * 16 + 8 * h) * 2);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xb[ks], s, 0, 0, 0);
-    }
-
-    // ---- 2. kernel values on the VALU; target on the lane, 16 sources in registers
-    const int64_t j0 = t * MFMA_TILE;
-    bool check = false;
-    if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
-    float p[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float k = mfma_kval<KERNEL>(s[q]);
-      if constexpr (KERNEL == K_INVDIST) {
-        if (check) k = (j0 + acc_row(q, h) == jz) ? 0.f : k;
-      }
-      p[q] = k;
-      den += k;
-    }
-
-    // ---- 3. O[i][e] += sum_j P[j][i] V[j][e]: P registers are the A operand
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pa;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pa[j] = (__bf16)p[8 * s2 + j];
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const unsigned char* row = lv + (nt * 32 + r) * MFMA_V_STRIDE;
         const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 4 * h) * 2);
         const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 8 + 4 * h) * 2);
-        bf16x8 vb;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          vb[j] = v0[j];
-          vb[4 + j] = v1[j];
+          vb[s2][nt][j] = v0[j];
+          vb[s2][nt][4 + j] = v1[j];
         }
-        o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb, o[nt], 0, 0, 0);
+      }
+    const int64_t j0 = t * MFMA_TILE;
+    bool check = false;
+    if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
+
+#pragma unroll
+    for (int w = 0; w < TW; ++w) {
+      // ---- 1. S[j][i]: KS MFMAs, A = source rows (row r of the tile), B = targets
+      f32x16 s;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s[q] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[ks], xb[w][ks], s, 0, 0, 0);
+
+      // ---- 2. kernel values on the VALU; target on the lane, 16 sources in registers
+      float p[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float k = mfma_kval<KERNEL>(s[q]);
+        if constexpr (KERNEL == K_INVDIST) {
+          if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
+        }
+        p[q] = k;
+        den[w] += k;
+      }
+
+      // ---- 3. O[i][e] += sum_j P[j][i] V[j][e]: P registers are the A operand
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pa;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pa[j] = (__bf16)p[8 * s2 + j];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          o[w][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, vb[s2][nt], o[w][nt], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -219,13 +241,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
 
   // ---- epilogue: numerators [segment][target][column] (128-byte rows per register),
   // denominators: the two lane halves hold the two halves of each target's sources
-  den += __shfl_xor(den, 32);
-  float* part = a.part + ((int64_t)seg * a.n_pad + i0) * (NT * 32);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int w = 0; w < TW; ++w) {
+    const float dsum = den[w] + __shfl_xor(den[w], 32);
+    float* part = a.part + ((int64_t)seg * a.n_pad + i0 + w * MFMA_TILE) * (NT * 32);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) part[(int64_t)acc_row(q, h) * (NT * 32) + nt * 32 + r] = o[nt][q];
-  if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + r] = den;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) part[(int64_t)acc_row(q, h) * (NT * 32) + nt * 32 + r] = o[w][nt][q];
+    if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = dsum;
+  }
 }
 
 }  // namespace kmvp

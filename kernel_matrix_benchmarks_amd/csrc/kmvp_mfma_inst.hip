@@ -11,35 +11,38 @@
 namespace kmvp {
 
 template <int KS, int NT>
-static hipError_t launch_one(const MfmaArgs& args, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL((mfma_kernel<KMVP_KERNEL, KS, NT>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+static hipError_t launch_one(int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream) {
+  if (TW == 2)
+    hipLaunchKernelGGL((mfma_kernel<KMVP_KERNEL, KS, NT, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+  else
+    hipLaunchKernelGGL((mfma_kernel<KMVP_KERNEL, KS, NT, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args);
   return hipGetLastError();
 }
 
 template <int KS>
-static hipError_t launch_nt(int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream) {
+static hipError_t launch_nt(int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream) {
   switch (NT) {
-    case 1: return launch_one<KS, 1>(args, grid, stream);
-    case 2: return launch_one<KS, 2>(args, grid, stream);
-    case 3: return launch_one<KS, 3>(args, grid, stream);
-    case 4: return launch_one<KS, 4>(args, grid, stream);
+    case 1: return launch_one<KS, 1>(TW, args, grid, stream);
+    case 2: return launch_one<KS, 2>(TW, args, grid, stream);
+    case 3: return launch_one<KS, 3>(TW, args, grid, stream);
+    case 4: return launch_one<KS, 4>(TW, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t KMVP_FN(int KS, int NT, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+hipError_t KMVP_FN(int KS, int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream,
                    const char** kernel_name) {
   if (kernel_name) *kernel_name = "mfma_kernel";
   switch (KS) {
-    case 1: return launch_nt<1>(NT, args, grid, stream);
-    case 2: return launch_nt<2>(NT, args, grid, stream);
-    case 3: return launch_nt<3>(NT, args, grid, stream);
-    case 4: return launch_nt<4>(NT, args, grid, stream);
-    case 5: return launch_nt<5>(NT, args, grid, stream);
-    case 6: return launch_nt<6>(NT, args, grid, stream);
-    case 7: return launch_nt<7>(NT, args, grid, stream);
-    case 8: return launch_nt<8>(NT, args, grid, stream);
-    case 9: return launch_nt<9>(NT, args, grid, stream);
+    case 1: return launch_nt<1>(NT, TW, args, grid, stream);
+    case 2: return launch_nt<2>(NT, TW, args, grid, stream);
+    case 3: return launch_nt<3>(NT, TW, args, grid, stream);
+    case 4: return launch_nt<4>(NT, TW, args, grid, stream);
+    case 5: return launch_nt<5>(NT, TW, args, grid, stream);
+    case 6: return launch_nt<6>(NT, TW, args, grid, stream);
+    case 7: return launch_nt<7>(NT, TW, args, grid, stream);
+    case 8: return launch_nt<8>(NT, TW, args, grid, stream);
+    case 9: return launch_nt<9>(NT, TW, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }
