@@ -57,3 +57,37 @@ ALL_METRICS = {
     "total-time": lambda error, properties: total_time(properties),
     "memory-footprint": lambda error, properties: memory_footprint(properties),
 }
+
+
+# every metric of the reference is "lower is better" (worst = +inf, metrics.py:87-128)
+def pareto_front(points):
+    """Pareto frontier of (label, x, y) triples, both metrics lower-is-better.
+
+    Restates ``plotting/utils.create_pointset`` (utils.py:15-76): sort from the best to
+    the worst y (ties on x), sweep, keep every point whose x beats the best x seen so far.
+    Returns ``{"front": {"x", "y", "labels"}, "all": {...}}`` like the reference."""
+    data = sorted(points, key=lambda t: (t[2], t[1]))
+    out = {"front": {"x": [], "y": [], "labels": []}, "all": {"x": [], "y": [], "labels": []}}
+    best_x = float("inf")
+    for label, xv, yv in data:
+        out["all"]["x"].append(xv)
+        out["all"]["y"].append(yv)
+        out["all"]["labels"].append(label)
+        if xv < best_x:
+            best_x = xv
+            out["front"]["x"].append(xv)
+            out["front"]["y"].append(yv)
+            out["front"]["labels"].append(label)
+    return out
+
+
+def summarize_results(dataset, x_name="total-time", y_name="rmse-error", root="results"):
+    """(label, x, y) for every stored run of ``dataset`` and the Pareto front, with the
+    reference's default axes (plot.py:109-128)."""
+    from kernel_matrix_benchmarks_amd import results as _results
+
+    pts = []
+    for props, f in _results.load_all_results(dataset, root=root):
+        err = np.asarray(f["error"][:])
+        pts.append((props.get("name", "?"), ALL_METRICS[x_name](err, props), ALL_METRICS[y_name](err, props)))
+    return pts, pareto_front(pts)

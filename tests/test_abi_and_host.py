@@ -153,6 +153,15 @@ def test_metrics_definition():
     assert metrics.ALL_METRICS["max-error"](err, props) == 5.0
 
 
+def test_pareto_front_rule():
+    # utils.py:15-76: sweep from the best y, keep points that improve the best x so far
+    pts = [("a", 1.0, 5.0), ("b", 2.0, 3.0), ("c", 3.0, 4.0), ("d", 4.0, 1.0), ("e", 0.5, 6.0)]
+    out = metrics.pareto_front(pts)
+    assert out["all"]["labels"] == ["d", "b", "c", "a", "e"]
+    assert out["front"]["labels"] == ["d", "b", "a", "e"]  # c is dominated by b
+    assert out["front"]["x"] == [4.0, 2.0, 1.0, 0.5]
+
+
 class OracleBackedProduct(base.BaseProduct):
     """TEST-ONLY plugin (lives in tests/): lets the runner protocol be exercised on a
     machine without a GPU.  Not part of the product."""
@@ -219,3 +228,5 @@ def test_runner_protocol_and_result_files(tmp_path):
         assert metrics.result_errors(err)["max"] < 1e-12  # fp64 run reproduces the dataset
     finally:
         f.close()
+    pts, front = metrics.summarize_results(name, root=str(tmp_path / "results"))
+    assert len(pts) == 2 and len(front["front"]["labels"]) >= 1
