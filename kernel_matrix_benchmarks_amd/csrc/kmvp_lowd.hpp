@@ -71,15 +71,49 @@ __device__ __forceinline__ float kval(float s) {
     return __builtin_amdgcn_rsqf(s);  // 1/sqrt(0) = inf, as the reference's 1/np.sqrt
   }
 }
+// exp(-s) in double precision for s >= 0 without the math library's general-purpose exp
+// (gfx950 has no fp64 transcendental instruction; ocml's exp costs ~30 fp64 operations):
+//   -s = (64 m + j) ln2/64 + r ,  |r| <= ln2/128
+//   exp(-s) = 2^m * 2^(j/64) * exp(r)
+// with 2^(j/64) from a 64-entry table in LDS (filled once per workgroup) and exp(r) as its
+// degree-5 Taylor polynomial (r^6/720 < 4e-17).  Two-constant Cody-Waite reduction keeps r
+// exact to ~1e-19 for s < 800; larger s (incl. the +inf of pad records) are clamped there and
+// return exactly 0, like exp(): ldexp underflows below 2^-1074.
+__device__ __forceinline__ double kexp_neg_f64(double s, const double* __restrict__ tab) {
+  s = fmin(s, 800.0);
+  const double n = rint(s * (-92.332482616893657));      // -64 / ln 2
+  double r = fma(n, -0.010830424696905538, -s);  // ln2/64, high 30 bits: n * hi is exact
+  r = fma(n, 6.563929801064195e-13, r);          // ln2/64 - hi = -6.56e-13
+  const int ni = (int)n;
+  const double t = tab[ni & 63];
+  double p = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(t * p, ni >> 6);
+}
+
 template <int KERNEL>
-__device__ __forceinline__ double kval(double s) {
+__device__ __forceinline__ double kval(double s, const double* __restrict__ tab) {
   if constexpr (KERNEL == K_GAUSSIAN) {
-    return exp(-s);
+    return kexp_neg_f64(s, tab);
   } else if constexpr (KERNEL == K_ABSEXP) {
-    return exp(-sqrt(s));
+    return kexp_neg_f64(sqrt(s), tab);
   } else {
-    return 1.0 / sqrt(s);
+    // 1/sqrt(s): hardware estimate (v_rsq_f64, ~26 bits) + two Newton steps; the estimate is
+    // already exact for s = 0 (inf, as the reference's 1/np.sqrt) and s = inf (0, pad records)
+    const double y0 = __builtin_amdgcn_rsq(s);
+    double e = fma(-s * y0, y0, 1.0);
+    double y = fma(y0 * e, 0.5, y0);
+    e = fma(-s * y, y, 1.0);
+    y = fma(y * e, 0.5, y);
+    return (s == 0.0 || s == (double)INFINITY) ? y0 : y;
   }
+}
+template <int KERNEL>
+__device__ __forceinline__ float kval(float s, const double*) {
+  return kval<KERNEL>(s);
 }
 
 // coordinate pre-scale that turns exp() into the hardware's exp2()
@@ -124,7 +158,7 @@ struct RecLayout {
 template <int KERNEL, int D, int E, int SIG, int T, bool CHECK_DIAG, typename real>
 __device__ __forceinline__ void interact(const real (&x)[T][D], real (&acc)[T][RecLayout<D, E, SIG>::NE],
                                          const real* __restrict__ r, const int64_t (&jz)[T],
-                                         int64_t j_local) {
+                                         int64_t j_local, const double* __restrict__ tab) {
   using L = RecLayout<D, E, SIG>;
   real y[D];
 #pragma unroll
@@ -141,7 +175,7 @@ __device__ __forceinline__ void interact(const real (&x)[T][D], real (&acc)[T][R
       df = x[t][d] - y[d];
       s = fma(df, df, s);
     }
-    real k = kval<KERNEL>(s);
+    real k = kval<KERNEL>(s, tab);
     if constexpr (CHECK_DIAG) k = (j_local == jz[t]) ? (real)0 : k;
     if constexpr (SIG == SIG_DENSITY) {
       acc[t][0] += k;
@@ -160,6 +194,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_kernel(const LowdArgs<real
   constexpr int NE = L::NE;
   constexpr int U = 4;  // sources per batch; segments start on batch boundaries
   constexpr bool F32 = sizeof(real) == 4;
+
+  // fp64 only: table 2^(j/64) of kexp_neg_f64
+  __shared__ double exp_tab_lds[F32 ? 1 : 64];
+  const double* exp_tab = exp_tab_lds;
+  if constexpr (!F32) {
+    if (threadIdx.x < 64) exp_tab_lds[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+  }
 
   int tb, seg;
   block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
@@ -247,11 +289,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_kernel(const LowdArgs<real
       if (check) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          interact<KERNEL, D, E, SIG, T, true, real>(x, acc, rb + u * R, jzl, (int64_t)(j + u));
+          interact<KERNEL, D, E, SIG, T, true, real>(x, acc, rb + u * R, jzl, (int64_t)(j + u), exp_tab);
       } else {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          interact<KERNEL, D, E, SIG, T, false, real>(x, acc, rb + u * R, jzl, (int64_t)(j + u));
+          interact<KERNEL, D, E, SIG, T, false, real>(x, acc, rb + u * R, jzl, (int64_t)(j + u), exp_tab);
       }
     };
     real ra[U * R], rb[U * R];
@@ -315,11 +357,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_kernel(const LowdArgs<real
         if (check) {
 #pragma unroll
           for (int u = 0; u < U; ++u)
-            interact<KERNEL, D, E, SIG, T, true, real>(x, acc, lrec + (jj + u) * R, jz, j + u);
+            interact<KERNEL, D, E, SIG, T, true, real>(x, acc, lrec + (jj + u) * R, jz, j + u, exp_tab);
         } else {
 #pragma unroll
           for (int u = 0; u < U; ++u)
-            interact<KERNEL, D, E, SIG, T, false, real>(x, acc, lrec + (jj + u) * R, jz, j + u);
+            interact<KERNEL, D, E, SIG, T, false, real>(x, acc, lrec + (jj + u) * R, jz, j + u, exp_tab);
         }
       }
       since_fold += LDS_TILE;
@@ -360,6 +402,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
     int64_t j_offset, int64_t m_total, int x_in_lds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   real* xl = reinterpret_cast<real*>(dyn_lds);  // [D][BLOCK_THREADS] when it fits in LDS
+  __shared__ double exp_tab_lds[sizeof(real) == 4 ? 1 : 64];
+  const double* exp_tab = exp_tab_lds;
+  if constexpr (sizeof(real) == 8) {
+    if (threadIdx.x < 64) exp_tab_lds[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+  }
   const int seg = (int)(blockIdx.x % segments);
   const int64_t tb = blockIdx.x / segments;
   const int64_t i = tb * BLOCK_THREADS + threadIdx.x;
@@ -393,7 +441,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
           s = fma(df, df, s);
         }
       }
-      real k = kval<KERNEL>(s);
+      real k = kval<KERNEL>(s, exp_tab);
       if constexpr (KERNEL == K_INVDIST) k = (j == jz) ? (real)0 : k;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
