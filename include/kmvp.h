@@ -116,6 +116,10 @@ int kmvp_gaussian_cg_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, int
                            double* out_b, int* iters, double* resid);
 int kmvp_absexp_cg_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, int maxit,
                          double* out_b, int* iters, double* resid);
+/* Same contract for the inverse-distance kernel, whose matrix (zero diagonal,
+ * bruteforce.py:13-14) is symmetric but INDEFINITE: MINRES instead of CG. */
+int kmvp_invdist_minres_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, int maxit,
+                              double* out_b, int* iters, double* resid);
 
 /* Source sharding over the GPUs of one node, one process per GPU:
  * rank 0 calls kmvp_comm_get_unique_id and hands the 128 bytes to every rank

@@ -39,6 +39,8 @@ SYMBOLS = [
                                           _c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
     ("kmvp_absexp_cg_solve", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_int,
                                         _c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
+    ("kmvp_invdist_minres_solve", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_int,
+                                             _c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
     ("kmvp_comm_get_unique_id", _c.c_int, [_c.c_void_p]),
     ("kmvp_comm_init", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
     ("kmvp_set_option", _c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_int64]),
@@ -148,9 +150,10 @@ class Context:
         entry = {
             "gaussian": self._lib.kmvp_gaussian_cg_solve,
             "absolute-exponential": self._lib.kmvp_absexp_cg_solve,
+            "inverse-distance": self._lib.kmvp_invdist_minres_solve,  # indefinite: MINRES
         }.get(kernel)
         if entry is None:
-            raise NotImplementedError(f"no CG solver for kernel {kernel} (not positive definite)")
+            raise NotImplementedError(f"no solver for kernel {kernel}")
         M, E = a.shape
         out = np.empty((M, E), dtype=np.float64)
         iters = ctypes.c_int(0)

@@ -149,14 +149,15 @@ class MI355XProduct(BaseProduct):
 
 
 class MI355XSolver(BaseSolver):
-    """Solves K b = a by conjugate gradients with the HIP product as the operator."""
+    """Solves K b = a with the HIP product as the operator: conjugate gradients for the positive
+    definite Gaussian / exp(-r) matrices, MINRES for the symmetric indefinite inverse-distance
+    matrix (zero diagonal, bruteforce.py:13-14)."""
 
     def __init__(self, *, kernel, dimension, normalize_rows=False, precision=np.float64,
                  device=0, rtol=1e-6, maxit=1000):
         super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows,
                          precision=precision)
-        if kernel not in ("gaussian", "absolute-exponential"):
-            # inverse-distance with a zeroed diagonal is indefinite (SURVEY F11): CG does not apply
+        if kernel not in SUPPORTED_KERNELS:
             raise NotImplementedError(f"MI355XSolver doesn't support kernel {kernel}.")
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)
         if self._dtype_code == _lib.KMVP_BF16:
@@ -168,7 +169,8 @@ class MI355XSolver(BaseSolver):
         self.iterations = 0
         self.residual = float("nan")
         self.converged = False
-        self.name = f"MI355XSolver({_precision_name(precision)}, rtol={rtol:g})"
+        self.method = "minres" if kernel == "inverse-distance" else "cg"
+        self.name = f"MI355XSolver({_precision_name(precision)}, {self.method}, rtol={rtol:g})"
 
     def prepare_data(self, *, source_points):
         y = np.ascontiguousarray(source_points, dtype=self._host_dtype)

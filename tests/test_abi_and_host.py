@@ -51,7 +51,9 @@ def test_constructor_contract():
     with pytest.raises(NotImplementedError):  # bruteforce.py:82-85
         mi355x.MI355XProduct(kernel="laplacian", dimension=3)
     with pytest.raises(NotImplementedError):
-        mi355x.MI355XSolver(kernel="inverse-distance", dimension=3)
+        mi355x.MI355XSolver(kernel="laplacian", dimension=3)
+    assert mi355x.MI355XSolver(kernel="inverse-distance", dimension=3).method == "minres"
+    assert mi355x.MI355XSolver(kernel="gaussian", dimension=3).method == "cg"
     with pytest.raises(NotImplementedError):
         mi355x.MI355XProduct(kernel="gaussian", dimension=3, precision="float16")
     p = mi355x.MI355XProduct(kernel="gaussian", dimension=3, normalize_rows=True, precision="float32")
@@ -82,7 +84,9 @@ def test_registry_expansion_rules():
     assert definitions.get_definitions(hardware="CPU") == []
     sol = definitions.get_definitions(task="solver", dataset="solver-cube-D3-E1-M1000-N1000-gaussian")
     assert [s.constructor for s in sol] == ["MI355XSolver"] * 2
-    assert definitions.get_definitions(task="solver", dataset="solver-sphere-D3-E1-M1000-N1000-inverse-distance") == []
+    inv = definitions.get_definitions(task="solver", kernel="inverse-distance",
+                                      dataset="solver-sphere-D3-E1-M1000-N1000-inverse-distance")
+    assert [d.arguments["kernel"] for d in inv] == ["inverse-distance"] * 2  # the reference's solver datasets
     att = definitions.get_definitions(task="attention", normalize_rows=True)
     assert att and all(a.arguments["normalize_rows"] for a in att)
 

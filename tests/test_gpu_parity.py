@@ -346,6 +346,29 @@ def test_cg_solver_reaches_the_residual(expected):
         assert abs(res - info["cg_relative_residual"]) <= 1e-9
 
 
+def test_minres_solver_on_the_references_sphere_datasets():
+    """solver-sphere-*-inverse-distance (datasets.py:393-399): symmetric indefinite matrix -> MINRES."""
+    for n in (500, 2000):
+        y = kmvp_oracle.uniform_sphere_points(n)
+        b_true = np.random.RandomState(n).randn(n, 2)
+        a = kmvp_oracle.product(kernel="inverse-distance", source_points=y, source_signal=b_true)
+        algo = MI355XSolver(kernel="inverse-distance", dimension=3, precision=np.float64, rtol=1e-8, maxit=20000)
+        try:
+            algo.prepare_data(source_points=y)
+            algo.fit()
+            algo.prepare_query(target_signal=a)
+            algo.query()
+            sol = algo.get_result()
+            info = algo.get_additional()
+        finally:
+            algo.done()
+        res = kmvp_oracle.relative_residual(kernel="inverse-distance", source_points=y, solution=sol, target_signal=a)
+        assert info["cg_converged"] and res <= 2e-8, (n, res, info)
+        # this matrix is well conditioned enough for the iterate to match the dense lstsq answer
+        ref = kmvp_oracle.solve(kernel="inverse-distance", source_points=y, target_signal=a)
+        assert np.max(np.abs(sol - ref)) <= 1e-5 * np.max(np.abs(ref)), np.max(np.abs(sol - ref))
+
+
 def test_cg_solver_config5_shape_small():
     """Config 5 recipe (gaussian, D=3, fp64, a := K b) at n = 20000: residual < 1e-6."""
     n = 20000
@@ -411,13 +434,15 @@ def test_runner_end_to_end_on_gpu(tmp_path):
 def test_runner_solver_dataset_on_gpu(tmp_path):
     from kernel_matrix_benchmarks_amd import runner
 
-    name = "solver-cube-D3-E1-M400-N400-absolute-exponential"
-    stored = runner.run_dataset(name, hardware="GPU", runs=1, data_root=str(tmp_path / "data"),
-                                results_root=str(tmp_path / "results"), verbose=False)
-    assert len(stored) == 2
-    for fn, attrs, result in stored:
-        assert attrs["algo"] == "mi355x-solver" and result.shape == (400, 1)
-        assert attrs["cg_converged"] and attrs["cg_relative_residual"] <= (1e-6 if "float64" in attrs["name"] else 1e-4)
+    for name in ("solver-cube-D3-E1-M400-N400-absolute-exponential",
+                 "solver-sphere-D3-E1-M400-N400-inverse-distance"):  # the reference's dataset family
+        stored = runner.run_dataset(name, hardware="GPU", runs=1, data_root=str(tmp_path / "data"),
+                                    results_root=str(tmp_path / "results"), verbose=False)
+        assert len(stored) == 2
+        for fn, attrs, result in stored:
+            assert attrs["algo"] == "mi355x-solver" and result.shape == (400, 1)
+            assert attrs["cg_converged"], attrs
+            assert attrs["cg_relative_residual"] <= (1e-6 if "float64" in attrs["name"] else 1e-4)
 
 
 def test_rccl_binds_to_the_hip_runtime_in_use():
