@@ -147,29 +147,29 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         algo.query()  # pair loop + segment reduction + [RCCL all-reduce] + finish, then stream sync
-        kernel_ms.append(algo._ctx.last_kernel_ms)
+        kernel_ms.append(algo.device_kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    total_ms = algo._ctx.last_total_ms
+    total_ms = algo.device_total_ms
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
     a = algo.get_result()
-    kname = algo._ctx.last_kernel_name
+    kname = algo.device_kernel
     # the other squared-distance form on the same resident data, for the record (3 steps, untimed region)
     other = None
     if args.sqdists == "auto" and kname == "fast_kernel" and world == 1:
-        algo._ctx.set_option("fast_sqdists", 0)
+        algo.set_query_arguments(fast_sqdists=0)
         algo.query()
         oms = []
         for _ in range(3):
             algo.query()
-            oms.append(algo._ctx.last_kernel_ms)
-        other = {"kernel": algo._ctx.last_kernel_name, "kernel_ms": float(np.mean(oms)),
+            oms.append(algo.device_kernel_ms)
+        other = {"kernel": algo.device_kernel, "kernel_ms": float(np.mean(oms)),
                  "pairs_per_s": float(n) * float(n) / (float(np.mean(oms)) * 1e-3)}
-        algo._ctx.set_option("fast_sqdists", -1)
+        algo.set_query_arguments(fast_sqdists=-1)
     max_err = rel_err = None
     if rank == 0:
         # max |err| against the float64 oracle on a fixed sample of rows (BASELINE metric's error leg)
@@ -185,7 +185,7 @@ def main():
         pairs = float(n) * float(n)
         sec_per_step = elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
-        shard_pairs = float(n) * float(algo._shard[1] - algo._shard[0])
+        shard_pairs = float(n) * float(algo.shard[1] - algo.shard[0])
         flops = FLOPS_PER_PAIR[kernel] * shard_pairs
         achieved_tflops = flops / (k_ms * 1e-3) / 1e12
         traffic = None
@@ -236,10 +236,10 @@ def main():
                 "mfma_frac": (MFMA_FLOPS_PER_PAIR_FAST * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
                               if kname == "fast_kernel" else 0.0),
                 # north-star's "HBM" reading: bytes every wavefront streams from the source block
-                "source_stream_GBps": tiles * float(algo._shard[1] - algo._shard[0]) * (D + E) * 4 / (k_ms * 1e-3) / 1e9,
-                "source_stream_frac_of_hbm_peak": tiles * float(algo._shard[1] - algo._shard[0]) * (D + E) * 4
+                "source_stream_GBps": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4 / (k_ms * 1e-3) / 1e9,
+                "source_stream_frac_of_hbm_peak": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4
                                                   / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                "algorithmic_hbm_bytes": 4 * (n * D + (algo._shard[1] - algo._shard[0]) * (D + E) + n * E),
+                "algorithmic_hbm_bytes": 4 * (n * D + (algo.shard[1] - algo.shard[0]) * (D + E) + n * E),
             },
         }
         out["config"]["sqdists"] = ("expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "

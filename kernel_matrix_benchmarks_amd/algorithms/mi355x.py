@@ -125,6 +125,23 @@ class MI355XProduct(BaseProduct):
         """Device kB held by the context (the RSS of the reference says nothing here)."""
         return 0.0 if self._ctx is None else self._ctx.device_bytes / 1024
 
+    # HIP-event timings of the last query() (device side) and the source slice this rank owns
+    @property
+    def device_kernel_ms(self):
+        return self._ctx.last_kernel_ms
+
+    @property
+    def device_total_ms(self):
+        return self._ctx.last_total_ms
+
+    @property
+    def device_kernel(self):
+        return self._ctx.last_kernel_name
+
+    @property
+    def shard(self):
+        return self._shard
+
     def get_additional(self):
         if self._ctx is None:
             return {}
@@ -154,7 +171,7 @@ class MI355XSolver(BaseSolver):
     matrix (zero diagonal, bruteforce.py:13-14)."""
 
     def __init__(self, *, kernel, dimension, normalize_rows=False, precision=np.float64,
-                 device=0, rtol=1e-6, maxit=1000):
+                 device=0, rtol=1e-6, maxit=10000):
         super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows,
                          precision=precision)
         if kernel not in SUPPORTED_KERNELS:

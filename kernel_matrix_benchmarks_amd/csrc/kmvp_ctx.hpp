@@ -1,0 +1,165 @@
+// Shared host-side state of libkmvp.so: the per-GPU context, small helpers and the
+// functions the translation units call across each other.
+//   kmvp_api.hip      the extern "C" surface of include/kmvp.h
+//   kmvp_product.hip  layouts, launch geometry and the three pair-loop paths
+//   kmvp_solvers.hip  conjugate gradients and MINRES on the product
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen'ed on first use
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/kmvp.h"
+#include "kmvp_internal.hpp"
+
+namespace kmvp {
+
+// which path's layouts the shared xs / rec buffers hold
+enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2 };
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+// RCCL entry points, resolved lazily so that single-GPU use never loads the library
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error, path;
+  bool load() {
+    if (handle) return true;
+    // RCCL must drive the SAME HIP runtime as this library: a process may hold two ROCm
+    // stacks (e.g. the system one and the copy bundled with PyTorch), and a bare
+    // dlopen("librccl.so.1") returns whichever copy happens to be loaded already.  So look
+    // next to the libamdhip64 this library is bound to first, by absolute path.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+      char resolved[4096];
+      std::string hip_path = realpath(info.dli_fname, resolved) ? resolved : info.dli_fname;
+      const size_t slash = hip_path.rfind('/');
+      if (slash != std::string::npos) {
+        const std::string dir = hip_path.substr(0, slash + 1);
+        names.push_back(dir + "librccl.so.1");
+        names.push_back(dir + "librccl.so");
+      }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& n : names) {
+      handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (handle) {
+        path = n;
+        break;
+      }
+    }
+    if (!handle) {
+      error = std::string("cannot load librccl: ") + dlerror();
+      return false;
+    }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(handle, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
+    AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+    CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+    GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+      error = "librccl lacks an expected symbol";
+      return false;
+    }
+    return true;
+  }
+};extern Rccl g_rccl;
+
+}  // namespace kmvp
+
+struct kmvp_ctx {
+  using DevBuf = kmvp::DevBuf;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  std::string err;
+
+  // problem
+  int dtype = -1;
+  int D = 0, E = 0;
+  int64_t M = 0, N = 0, j_offset = 0, m_total = 0;
+  bool same_points = false;
+  bool have_points = false, have_signal = false, density = false;
+
+  DevBuf y_raw, x_raw, b_raw;   // caller's arrays in the working precision
+  DevBuf xs, rec;               // kernel layouts (specialised path; bf16 path: augmented targets, tile images)
+  DevBuf partd;                 // bf16 path: partial denominators
+  DevBuf aux;                   // fast path: |x'|^2 per target + cloud centre
+  DevBuf x_scaled, y_scaled;    // scaled copies (generic path)
+  DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
+  DevBuf scratch;               // CG vectors / dot products
+  uint64_t points_ver = 0, signal_ver = 0;
+  // what xs / rec / scaled copies currently hold
+  int packed_layout = -1;  // LAYOUT_* of the path that owns xs / rec right now
+  int packed_kernel = -1, packed_sig = -1, packed_T = -1;
+  uint64_t packed_points_ver = 0, packed_signal_ver = 0;
+  int gen_kernel = -1;
+  uint64_t gen_points_ver = 0;
+  int64_t out_n = 0;
+  int out_e = 0;
+
+  // tuning (kmvp_set_option)
+  int opt_feed = -1, opt_T = 0, opt_segments = 0, opt_chunk = 512;
+  int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always
+  float cloud_radius2 = INFINITY;          // squared half-diagonal of the clouds' bounding box
+  uint64_t centre_ver = 0;
+
+  // sharding
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+
+  float last_kernel_ms = 0.f, last_total_ms = 0.f;
+  const char* last_kernel_name = "";
+};
+
+namespace kmvp {
+
+int fail(kmvp_ctx* c, int code, const std::string& msg);
+const char* create_error();
+
+#define HIP_TRY(c, expr)                                                                     \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return kmvp::fail((c), e_ == hipErrorOutOfMemory ? KMVP_E_NOMEM : KMVP_E_DEVICE,       \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+inline int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+inline size_t elem_size(int dtype) { return dtype == KMVP_F64 ? 8 : 4; }
+inline unsigned blocks_for(int64_t n, int threads = 256) { return (unsigned)((n + threads - 1) / threads); }
+
+int ensure(kmvp_ctx* c, DevBuf& b, size_t bytes);  // grow-only device buffer
+void release(DevBuf& b);
+
+// kmvp_product.hip: the product a = K b [/ K 1] with everything query() times, and the
+// bounding box of the freshly uploaded clouds (asynchronous on the context's stream)
+int run_product(kmvp_ctx* c, int kernel, bool normalise);
+int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D);
+
+// kmvp_solvers.hip
+int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, int maxit, double* out_b,
+             int* iters, double* resid);
+int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, int maxit,
+                 double* out_b, int* iters, double* resid);
+
+}  // namespace kmvp

@@ -1,0 +1,523 @@
+// The product a = K b [/ K 1]: kernel layouts, launch geometry, the three pair-loop paths
+// (lowd_kernel / fast_kernel / mfma_kernel) and their common epilogue
+//   segment reduction -> [RCCL all-reduce over the source shards] -> normalise.
+// Reference call this serves: BruteForceProductBLAS.query (bruteforce.py:130-153).
+#include "kmvp_ctx.hpp"
+#include "kmvp_fast_pack.hpp"
+#include "kmvp_mfma_pack.hpp"
+
+namespace kmvp {
+namespace {
+
+template <typename real>
+hipError_t launch_lowd(int kernel, int D, int E, int sig, LowdTuning tune,
+                       const LowdArgs<real>& args, dim3 grid, hipStream_t s, const char** name);
+template <>
+hipError_t launch_lowd<float>(int kernel, int D, int E, int sig, LowdTuning tune,
+                              const LowdArgs<float>& args, dim3 grid, hipStream_t s,
+                              const char** name) {
+  switch (kernel) {
+    case K_GAUSSIAN: return launch_lowd_gaussian_f32(D, E, sig, tune, args, grid, s, name);
+    case K_ABSEXP: return launch_lowd_absexp_f32(D, E, sig, tune, args, grid, s, name);
+    default: return launch_lowd_invdist_f32(D, E, sig, tune, args, grid, s, name);
+  }
+}
+template <>
+hipError_t launch_lowd<double>(int kernel, int D, int E, int sig, LowdTuning tune,
+                               const LowdArgs<double>& args, dim3 grid, hipStream_t s,
+                               const char** name) {
+  switch (kernel) {
+    case K_GAUSSIAN: return launch_lowd_gaussian_f64(D, E, sig, tune, args, grid, s, name);
+    case K_ABSEXP: return launch_lowd_absexp_f64(D, E, sig, tune, args, grid, s, name);
+    default: return launch_lowd_invdist_f64(D, E, sig, tune, args, grid, s, name);
+  }
+}
+
+template <typename real>
+hipError_t launch_generic(int kernel, int sig, const real* x, const real* y, const real* b,
+                          double* part, int64_t n, int64_t n_pad, int64_t m, int D, int E, int NE,
+                          int segments, int64_t seg_len, int64_t j_offset, int64_t m_total,
+                          hipStream_t s, const char** name);
+template <>
+hipError_t launch_generic<float>(int kernel, int sig, const float* x, const float* y, const float* b,
+                                 double* part, int64_t n, int64_t n_pad, int64_t m, int D, int E,
+                                 int NE, int segments, int64_t seg_len, int64_t j_offset,
+                                 int64_t m_total, hipStream_t s, const char** name) {
+  switch (kernel) {
+    case K_GAUSSIAN:
+      return launch_lowd_gaussian_f32_generic(sig, x, y, b, part, n, n_pad, m, D, E, NE, segments,
+                                              seg_len, j_offset, m_total, s, name);
+    case K_ABSEXP:
+      return launch_lowd_absexp_f32_generic(sig, x, y, b, part, n, n_pad, m, D, E, NE, segments,
+                                            seg_len, j_offset, m_total, s, name);
+    default:
+      return launch_lowd_invdist_f32_generic(sig, x, y, b, part, n, n_pad, m, D, E, NE, segments,
+                                             seg_len, j_offset, m_total, s, name);
+  }
+}
+template <>
+hipError_t launch_generic<double>(int kernel, int sig, const double* x, const double* y,
+                                  const double* b, double* part, int64_t n, int64_t n_pad, int64_t m,
+                                  int D, int E, int NE, int segments, int64_t seg_len,
+                                  int64_t j_offset, int64_t m_total, hipStream_t s,
+                                  const char** name) {
+  switch (kernel) {
+    case K_GAUSSIAN:
+      return launch_lowd_gaussian_f64_generic(sig, x, y, b, part, n, n_pad, m, D, E, NE, segments,
+                                              seg_len, j_offset, m_total, s, name);
+    case K_ABSEXP:
+      return launch_lowd_absexp_f64_generic(sig, x, y, b, part, n, n_pad, m, D, E, NE, segments,
+                                            seg_len, j_offset, m_total, s, name);
+    default:
+      return launch_lowd_invdist_f64_generic(sig, x, y, b, part, n, n_pad, m, D, E, NE, segments,
+                                             seg_len, j_offset, m_total, s, name);
+  }
+}
+
+template <typename real>
+real scale_for(int kernel) {
+  switch (kernel) {
+    case K_GAUSSIAN: return coord_scale<K_GAUSSIAN, real>();
+    case K_ABSEXP: return coord_scale<K_ABSEXP, real>();
+    default: return coord_scale<K_INVDIST, real>();
+  }
+}
+
+// sums[e][i] = sum over segments (index order) of part[s][e][i]
+__global__ void reduce_segments_kernel(const double* __restrict__ part, double* __restrict__ sums,
+                                       int64_t count /* NE*n_pad */, int segments) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  double v = 0.0;
+  for (int s = 0; s < segments; ++s) v += part[(int64_t)s * count + q];
+  sums[q] = v;
+}
+
+// out[i*E + e] = sums[e][i]  (/ sums[E][i] when normalised)
+__global__ void finish_kernel(const double* __restrict__ sums, double* __restrict__ out, int64_t n,
+                              int64_t n_pad, int E, int normalise) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double den = normalise ? sums[(int64_t)E * n_pad + i] : 1.0;
+  for (int e = 0; e < E; ++e) {
+    const double v = sums[(int64_t)e * n_pad + i];
+    out[i * E + e] = normalise ? v / den : v;
+  }
+}
+
+__global__ void fill_kernel(double* p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+
+// Common tail of every path, after the path's own reduction has left sums[column][n_pad]
+// (fp64) in c->sums: one RCCL all-reduce over the source shards when a communicator is
+// attached, normalisation / transposition into (N,E), event bookkeeping, and the stream
+// synchronisation that makes the entry point synchronous (runner.py:138-140 times it).
+int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, int sig) {
+  int rc;
+  if (c->comm && c->world > 1) {
+    ncclResult_t r = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, ncclFloat64, ncclSum,
+                                      c->comm, c->stream);
+    if (r != ncclSuccess)
+      return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  }
+  if ((rc = ensure(c, c->out, (size_t)std::max<int64_t>(N, 1) * E * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1))), dim3(256), 0, c->stream,
+                     (const double*)c->sums.p, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
+  c->out_n = N;
+  c->out_e = E;
+  return KMVP_OK;
+}
+
+// Number of source segments of a launch (specialised kernels).  Three pulls:
+//  * L2 residency: with segments % 8 == 0 each XCD streams one segment at a time
+//    (block_to_work), so a segment of <= 2 MiB of records stays in its 4 MiB L2;
+//  * parallelism: tile_blocks * segments should be many rounds of the 2048 resident
+//    blocks (256 CUs x 8), which only matters when there are few target tiles;
+//  * the fp64 partial buffer segments * NE * n_pad * 8 bytes stays bounded.
+int choose_segments(const kmvp_ctx* c, int64_t tile_blocks, int64_t m_pad, int NE, int64_t n_pad,
+                    int64_t rec_bytes, int64_t min_seg) {
+  int64_t seg;
+  if (c->opt_segments > 0) {
+    seg = c->opt_segments;
+  } else {
+    const int64_t l2_seg_bytes = 2 << 20;
+    seg = 8 * std::max<int64_t>(1, (m_pad * rec_bytes + 8 * l2_seg_bytes - 1) / (8 * l2_seg_bytes));
+    const int64_t target_blocks = 16384;
+    const int64_t for_parallelism = (target_blocks + tile_blocks - 1) / tile_blocks;
+    if (for_parallelism > seg) seg = (for_parallelism + 7) / 8 * 8;
+    const int64_t cap_len = std::max<int64_t>(1, m_pad / min_seg);              // segment >= min_seg sources
+    const int64_t cap_mem = std::max<int64_t>(1, (int64_t)(4e9 / ((double)NE * n_pad * 8)));
+    seg = std::min(seg, std::min(cap_len, cap_mem));
+    if (seg >= 8) seg = seg / 8 * 8;
+  }
+  seg = std::max<int64_t>(1, std::min<int64_t>(seg, 65535));
+  return (int)seg;
+}
+
+// The whole product: everything query() times.  `sig` as in kmvp_lowd.hpp.
+template <typename real>
+int run_product_t(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D;
+  const int E = sig == SIG_DENSITY ? 1 : c->E;
+  const int NE = sig == SIG_NORM ? E + 1 : E;
+  const int64_t N = c->N, M = c->M;
+  const bool specialised = D <= LOWD_MAX_D && E <= LOWD_MAX_E;
+  const real scale = scale_for<real>(kernel);
+  const real* x_raw = (const real*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  int rc;
+
+  int64_t n_pad;
+  int segments;
+  int64_t seg_len;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if (specialised) {
+    LowdTuning tune;
+    tune.feed = c->opt_feed >= 0 ? c->opt_feed : DEFAULT_FEED;
+    tune.targets_per_lane = c->opt_T > 0 ? c->opt_T : (tune.feed == 1 ? DEFAULT_TARGETS_PER_LANE : 2);
+    const int T = tune.targets_per_lane;
+    const int EB = sig == SIG_DENSITY ? 0 : E;
+    const int R = (D + EB + 3) / 4 * 4;
+    const int64_t tile = 64 * (int64_t)T * WAVES_PER_BLOCK;
+    n_pad = round_up(std::max<int64_t>(N, 1), tile);
+    const int64_t tile_blocks = n_pad / tile;
+    const int64_t batch = 8;  // two ping-pong batches of 4 records
+    const int64_t m_pad = round_up(std::max<int64_t>(M, 1), batch);
+    segments = choose_segments(c, tile_blocks, m_pad, NE, n_pad, (int64_t)R * sizeof(real), 1024);
+    seg_len = round_up((m_pad + segments - 1) / segments, batch);
+    segments = (int)((m_pad + seg_len - 1) / seg_len);
+
+    // (re)pack the kernel layouts when the points, the signal, the kernel or T changed
+    const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                           c->packed_layout != LAYOUT_LOWD || c->packed_T != T;
+    const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+    if (pts_stale) {
+      if ((rc = ensure(c, c->xs, (size_t)D * n_pad * sizeof(real)))) return rc;
+      hipLaunchKernelGGL((pack_targets_kernel<real>), dim3(blocks_for(n_pad)), dim3(256), 0,
+                         c->stream, x_raw, (real*)c->xs.p, N, n_pad, D, scale);
+    }
+    if (sig_stale) {
+      // one spare batch behind the last record keeps the prefetch in bounds
+      if ((rc = ensure(c, c->rec, (size_t)(m_pad + batch) * R * sizeof(real)))) return rc;
+      hipLaunchKernelGGL((pack_sources_kernel<real>), dim3(blocks_for(m_pad + batch)), dim3(256), 0,
+                         c->stream, (const real*)c->y_raw.p, (const real*)c->b_raw.p,
+                         (real*)c->rec.p, M, m_pad + batch, D, EB, R, scale);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->packed_points_ver = c->points_ver;
+    c->packed_signal_ver = c->signal_ver;
+    c->packed_kernel = kernel;
+    c->packed_sig = sig;
+    c->packed_layout = LAYOUT_LOWD;
+    c->packed_T = T;
+
+    if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
+    LowdArgs<real> a;
+    a.xs = (const real*)c->xs.p;
+    a.rec = (const real*)c->rec.p;
+    a.part = (double*)c->part.p;
+    a.n = N;
+    a.n_pad = n_pad;
+    a.m_pad = m_pad;
+    a.seg_len = seg_len;
+    a.segments = segments;
+    a.tile_blocks = (int)tile_blocks;
+    a.chunk = (int)round_up(std::max(c->opt_chunk, 8), batch);
+    a.j_offset = c->j_offset;
+    a.m_total = c->m_total;
+    const int64_t nblocks = tile_blocks * segments;
+    if (nblocks > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    hipError_t le = launch_lowd<real>(kernel, D, E, sig, tune, a, dim3((unsigned)nblocks), c->stream,
+                                      &c->last_kernel_name);
+    if (le == hipErrorInvalidValue)
+      return fail(c, KMVP_E_UNSUPPORTED, "no kernel instantiated for this (D, E, targets_per_lane, feed)");
+    HIP_TRY(c, le);
+  } else {
+    // generic fallback: scaled copies of the points, one target per lane
+    n_pad = round_up(std::max<int64_t>(N, 1), BLOCK_THREADS);
+    if (c->gen_points_ver != c->points_ver || c->gen_kernel != kernel) {
+      if ((rc = ensure(c, c->y_scaled, (size_t)M * D * sizeof(real)))) return rc;
+      hipLaunchKernelGGL((scale_kernel<real>), dim3(blocks_for(M * D)), dim3(256), 0, c->stream,
+                         (const real*)c->y_raw.p, (real*)c->y_scaled.p, M * D, scale);
+      if (!c->same_points) {
+        if ((rc = ensure(c, c->x_scaled, (size_t)N * D * sizeof(real)))) return rc;
+        hipLaunchKernelGGL((scale_kernel<real>), dim3(blocks_for(N * D)), dim3(256), 0, c->stream,
+                           x_raw, (real*)c->x_scaled.p, N * D, scale);
+      }
+      HIP_TRY(c, hipGetLastError());
+      c->gen_points_ver = c->points_ver;
+      c->gen_kernel = kernel;
+    }
+    const int64_t tile_blocks = n_pad / BLOCK_THREADS;
+    segments = choose_segments(c, tile_blocks, M, NE, n_pad, (int64_t)D * sizeof(real), 256);
+    seg_len = (M + segments - 1) / segments;
+    segments = (int)((M + seg_len - 1) / seg_len);
+    if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
+    const real* xg = (const real*)(c->same_points ? c->y_scaled.p : c->x_scaled.p);
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, launch_generic<real>(kernel, sig, xg, (const real*)c->y_scaled.p,
+                                    sig == SIG_DENSITY ? nullptr : (const real*)c->b_raw.p,
+                                    (double*)c->part.p, N, n_pad, M, D, c->E, NE, segments, seg_len,
+                                    c->j_offset, c->m_total, c->stream, &c->last_kernel_name));
+  }
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+  // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
+  const int64_t count = (int64_t)NE * n_pad;
+  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->sums.p, count, segments);
+  HIP_TRY(c, hipGetLastError());
+  return finish_product(c, count, N, n_pad, E, sig);
+}
+
+// split-bf16 MFMA low-D path (kmvp_fast.hpp): float32, D <= 7, E == 1, selected by the
+// "fast_sqdists" option (the reference's constructor flag of the same name).
+int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D;
+  const int E = 1;
+  const int NE = sig == SIG_NORM ? 2 : 1;
+  const int EB = sig == SIG_DENSITY ? 0 : 1;
+  const int64_t N = c->N, M = c->M;
+  const int KS = fast_ksteps(D);
+  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : FAST_DEFAULT_TT;
+  const int64_t SB = fast_stage_bytes(KS, EB);
+  const float scale = scale_for<float>(kernel);
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int64_t tile = (int64_t)FAST_TILE * TT * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(N, tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t m_tiles = (M + FAST_TILE - 1) / FAST_TILE;
+  const int64_t m_stages = (m_tiles + FAST_STAGE - 1) / FAST_STAGE;
+  int rc;
+
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, SB, 4);
+  const int64_t seg_stages = (m_stages + segments - 1) / segments;
+  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                         c->packed_layout != LAYOUT_FAST || c->packed_T != TT;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  float* centre = (float*)c->aux.p;  // written by kmvp_set_points
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * KS * 16 * 2))) return rc;
+    hipLaunchKernelGGL(pack_fast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
+                       centre, (__bf16*)c->xs.p, N, n_pad, D, KS, scale);
+  }
+  if (sig_stale) {
+    if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
+    hipLaunchKernelGGL(pack_fast_sources_kernel, dim3(blocks_for(m_stages * FAST_STAGE * FAST_TILE)),
+                       dim3(256), 0, c->stream, (const float*)c->y_raw.p, (const float*)c->b_raw.p, centre,
+                       (unsigned char*)c->rec.p, M, m_stages, D, EB, KS, scale);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = kernel;
+  c->packed_sig = sig;
+  c->packed_layout = LAYOUT_FAST;
+  c->packed_T = TT;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
+  FastArgs a;
+  a.xa = (const __bf16*)c->xs.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.part = (double*)c->part.p;
+  a.n_pad = n_pad;
+  a.m_tiles = m_tiles;
+  a.m_stages = m_stages;
+  a.seg_stages = seg_stages;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.chunk_stages = std::max(1, c->opt_chunk / (FAST_TILE * FAST_STAGE));
+  a.j_offset = c->j_offset;
+  a.m_total = c->m_total;
+  const dim3 grid((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  hipError_t le;
+  switch (kernel) {
+    case K_GAUSSIAN: le = launch_fast_gaussian(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_fast_absexp(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_fast_invdist(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+  }
+  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
+  HIP_TRY(c, le);
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+  const int64_t count = (int64_t)NE * n_pad;
+  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->sums.p, count, segments);
+  HIP_TRY(c, hipGetLastError());
+  return finish_product(c, count, N, n_pad, E, sig);
+}
+
+// bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
+// to augmented bf16 rows / LDS tile images, sums come back as fp32 partials.
+int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D;
+  const int E = sig == SIG_DENSITY ? 1 : c->E;
+  const int NE = sig == SIG_NORM ? E + 1 : E;
+  const int64_t N = c->N, M = c->M;
+  const int KS = mfma_ksteps(D);
+  const int NT = (E + 31) / 32;
+  if (KS > MFMA_MAX_KS || NT > MFMA_MAX_NT)
+    return fail(c, KMVP_E_UNSUPPORTED, "bf16 MFMA path is instantiated for D <= 138 and E <= 128");
+  const int KD = 16 * KS;
+  const int NEP = NT * 32;
+  const int64_t IMG = mfma_image_bytes(KS, NT);
+  const float scale = scale_for<float>(kernel);
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int TW = c->opt_T == 1 ? 1 : 2;  // target tiles of 32 per wave ("targets_per_lane" option: 1 or 2)
+  const int64_t tile = (int64_t)MFMA_TILE * TW * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(N, tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t m_tiles = (M + MFMA_TILE - 1) / MFMA_TILE;
+  int rc;
+
+  // segments: enough workgroups for >= 4 per CU, at least 8 source tiles each
+  int64_t seg = c->opt_segments > 0 ? c->opt_segments : (1024 + tile_blocks - 1) / tile_blocks;
+  seg = std::max<int64_t>(1, std::min<int64_t>(seg, std::max<int64_t>(1, m_tiles / 8)));
+  if (seg >= 8) seg = seg / 8 * 8;
+  const int64_t seg_tiles = (m_tiles + seg - 1) / seg;
+  const int segments = (int)((m_tiles + seg_tiles - 1) / seg_tiles);
+
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                         c->packed_layout != LAYOUT_MFMA || c->packed_T != TW;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * KD * 2))) return rc;
+    hipLaunchKernelGGL(pack_mfma_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream,
+                       x_raw, (__bf16*)c->xs.p, N, n_pad, D, KD, scale);
+  }
+  if (sig_stale) {
+    if ((rc = ensure(c, c->rec, (size_t)m_tiles * IMG))) return rc;
+    hipLaunchKernelGGL(pack_mfma_sources_kernel, dim3(blocks_for(m_tiles * MFMA_TILE)), dim3(256), 0,
+                       c->stream, (const float*)c->y_raw.p,
+                       sig == SIG_DENSITY ? (const float*)nullptr : (const float*)c->b_raw.p,
+                       (unsigned char*)c->rec.p, M, m_tiles, D, E, KS, NT, scale);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = kernel;
+  c->packed_sig = sig;
+  c->packed_layout = LAYOUT_MFMA;
+  c->packed_T = TW;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * n_pad * NEP * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->partd, (size_t)segments * n_pad * sizeof(float)))) return rc;
+  MfmaArgs a;
+  a.xa = (const __bf16*)c->xs.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.part = (float*)c->part.p;
+  a.partd = (float*)c->partd.p;
+  a.n_pad = n_pad;
+  a.m_tiles = m_tiles;
+  a.seg_tiles = seg_tiles;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.j_offset = c->j_offset;
+  a.m_total = c->m_total;
+  const dim3 grid((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  hipError_t le;
+  switch (kernel) {
+    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_mfma_invdist(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
+  }
+  HIP_TRY(c, le);
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+  const int64_t count = (int64_t)NE * n_pad;
+  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(mfma_reduce_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                     (const float*)c->part.p, (const float*)c->partd.p, (double*)c->sums.p, n_pad, NEP,
+                     E, segments, sig == SIG_NORM ? 1 : 0);
+  HIP_TRY(c, hipGetLastError());
+  return finish_product(c, count, N, n_pad, E, sig);
+}
+
+}  // namespace
+
+// Centre and squared half-diagonal of the bounding box of the clouds just uploaded by
+// kmvp_set_points (float32, D <= 7 only: the inputs of the split-bf16 path and of its "auto"
+// rule).  The launch and the 4-byte read-back are queued on the context's stream; the caller
+// synchronises.
+int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D) {
+  c->cloud_radius2 = INFINITY;
+  if (dtype != KMVP_F32 || D > FAST_MAX_D || M <= 0 || N <= 0) return KMVP_OK;
+  int rc;
+  if ((rc = ensure(c, c->aux, 16 * sizeof(float)))) return rc;
+  hipLaunchKernelGGL(fast_center_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)c->y_raw.p, M,
+                     c->same_points ? (const float*)nullptr : (const float*)c->x_raw.p, N, D,
+                     (float*)c->aux.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(&c->cloud_radius2, (float*)c->aux.p + 8, sizeof(float), hipMemcpyDeviceToHost,
+                            c->stream));
+  c->centre_ver = c->points_ver + 1;  // kmvp_set_points bumps points_ver once the upload is complete
+  return KMVP_OK;
+}
+
+int run_product(kmvp_ctx* c, int kernel, bool normalise) {
+  if (!c) return KMVP_E_INVALID;
+  if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
+  if (!c->have_signal) return fail(c, KMVP_E_INVALID, "kmvp_set_signal has not been called");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->N == 0 || c->M == 0) {
+    // empty clouds: a = 0 (N,E); nothing to launch
+    const int E = c->density ? 1 : c->E;
+    int rc = ensure(c, c->out, (size_t)std::max<int64_t>(c->N, 1) * E * sizeof(double));
+    if (rc) return rc;
+    if (c->N > 0) {
+      hipLaunchKernelGGL(fill_kernel, dim3(blocks_for(c->N * E)), dim3(256), 0, c->stream,
+                         (double*)c->out.p, c->N * E,
+                         normalise ? std::nan("") : 0.0);  // 0/0 in the reference
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->out_n = c->N;
+    c->out_e = E;
+    c->last_kernel_ms = c->last_total_ms = 0.f;
+    return KMVP_OK;
+  }
+  if (c->density && normalise) {
+    // bruteforce.py:134-138: the rows of a normalised matrix sum to one
+    int rc = ensure(c, c->out, (size_t)c->N * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks_for(c->N)), dim3(256), 0, c->stream,
+                       (double*)c->out.p, c->N, 1.0);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->out_n = c->N;
+    c->out_e = 1;
+    c->last_kernel_ms = c->last_total_ms = 0.f;
+    c->last_kernel_name = "fill_kernel";
+    return KMVP_OK;
+  }
+  const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
+  if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
+  if (c->dtype == KMVP_F32 && c->D <= FAST_MAX_D && (c->density || c->E == 1) && c->centre_ver == c->points_ver) {
+    // "fast_sqdists": expanded squared distances on the matrix cores.  auto = only where the
+    // expansion is as accurate as the difference form to working precision: the Gaussian
+    // (smooth in s; exp(-sqrt(s)) and 1/sqrt(s) amplify the absolute error of s near
+    // coincident points, as they do in the reference's own fast form) on clouds whose scaled
+    // radius keeps eps32 * (|x'|^2 + |y'|^2) ~ 1e-6.
+    const float sc = scale_for<float>(kernel);
+    const bool accurate = kernel == K_GAUSSIAN && c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
+    if (c->opt_fast == 1 || (c->opt_fast < 0 && accurate)) return run_product_fast(c, kernel, sig);
+  }
+  if (c->dtype == KMVP_F64) return run_product_t<double>(c, kernel, sig);
+  return run_product_t<float>(c, kernel, sig);
+}
+
+
+}  // namespace kmvp

@@ -1,0 +1,373 @@
+// Krylov solvers for K b = a with the on-the-fly product as the operator: conjugate
+// gradients (SPD Gaussian / exp(-r) matrices) and MINRES (symmetric indefinite
+// inverse-distance matrix).  The reference solves densely with lstsq (bruteforce.py:205-207);
+// parity is judged on the residual.
+#include "kmvp_ctx.hpp"
+
+namespace kmvp {
+
+// ------------------------------------------------------------------------------------
+// conjugate gradients on K b = a with the on-the-fly product as the operator
+
+constexpr int CG_BLOCKS = 256;
+
+// partial[block][e] = sum over the block's rows of u[i][e] * v[i][e]
+__global__ void cg_dot_kernel(const double* __restrict__ u, const double* __restrict__ v, int64_t m,
+                              int E, double* __restrict__ partial) {
+  __shared__ double red[256];
+  for (int e = 0; e < E; ++e) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (int64_t)gridDim.x * blockDim.x)
+      acc += u[i * E + e] * v[i * E + e];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * E + e] = red[0];
+    __syncthreads();
+  }
+}
+
+// out[i][e] = u[i][e] + coef[e] * v[i][e]
+__global__ void cg_axpy_kernel(double* __restrict__ out, const double* __restrict__ u,
+                               const double* __restrict__ v, const double* __restrict__ coef,
+                               int64_t m, int E) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * E) return;
+  out[q] = u[q] + coef[q % E] * v[q];
+}
+
+template <typename real>
+__global__ void cg_cast_kernel(const double* __restrict__ in, real* __restrict__ out, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = (real)in[q];
+}
+template <typename real>
+__global__ void cg_widen_kernel(const real* __restrict__ in, double* __restrict__ out, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = (double)in[q];
+}
+
+struct CgWork {
+  double *x, *r, *p, *partial, *coef;
+};
+
+int cg_dots(kmvp_ctx* c, const double* u, const double* v, int64_t m, int E, const CgWork& w,
+            std::vector<double>& host_partial, std::vector<double>& out) {
+  hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, u, v, m, E, w.partial);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(host_partial.data(), w.partial, sizeof(double) * CG_BLOCKS * E,
+                            hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out.assign(E, 0.0);
+  for (int b = 0; b < CG_BLOCKS; ++b)
+    for (int e = 0; e < E; ++e) out[e] += host_partial[(size_t)b * E + e];
+  return KMVP_OK;
+}
+
+int cg_axpy(kmvp_ctx* c, double* out, const double* u, const double* v,
+            const std::vector<double>& coef, int64_t m, int E, const CgWork& w) {
+  HIP_TRY(c, hipMemcpyAsync(w.coef, coef.data(), sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // coef is a host temporary
+  hipLaunchKernelGGL(cg_axpy_kernel, dim3(blocks_for(m * E)), dim3(256), 0, c->stream, out, u, v,
+                     w.coef, m, E);
+  HIP_TRY(c, hipGetLastError());
+  return KMVP_OK;
+}
+
+// K applied to the device vector v (M,E) double; the result lands in c->out (M,E) double.
+int cg_apply(kmvp_ctx* c, int kernel, const double* v, int64_t m, int E) {
+  int rc = ensure(c, c->b_raw, (size_t)m * E * elem_size(c->dtype));
+  if (rc) return rc;
+  if (c->dtype == KMVP_F64)
+    hipLaunchKernelGGL((cg_cast_kernel<double>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream, v,
+                       (double*)c->b_raw.p, m * E);
+  else
+    hipLaunchKernelGGL((cg_cast_kernel<float>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream, v,
+                       (float*)c->b_raw.p, m * E);
+  HIP_TRY(c, hipGetLastError());
+  c->density = false;
+  c->E = E;
+  c->have_signal = true;
+  ++c->signal_ver;
+  return run_product(c, kernel, false);
+}
+
+int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, int maxit,
+             double* out_b, int* iters, double* resid) {
+  if (!c) return KMVP_E_INVALID;
+  if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
+  if (!c->same_points) return fail(c, KMVP_E_INVALID, "the solver needs x == y (pass x_or_null = NULL)");
+  if (c->world > 1) return fail(c, KMVP_E_UNSUPPORTED, "the solver is single-GPU in this build");
+  if (!a_host || !out_b || E < 1 || maxit < 0 || !(rtol > 0)) return fail(c, KMVP_E_INVALID, "bad solver arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t m = c->M;
+  const size_t vec = (size_t)m * E * sizeof(double);
+  int rc = ensure(c, c->scratch, 3 * vec + sizeof(double) * (CG_BLOCKS + 1) * E);
+  if (rc) return rc;
+  CgWork w;
+  w.x = (double*)c->scratch.p;
+  w.r = w.x + (size_t)m * E;
+  w.p = w.r + (size_t)m * E;
+  w.partial = w.p + (size_t)m * E;
+  w.coef = w.partial + (size_t)CG_BLOCKS * E;
+  std::vector<double> hp((size_t)CG_BLOCKS * E), rs, rs_new, pap, anorm2, coef(E);
+
+  // r = p = a (widened to double), x = 0
+  rc = ensure(c, c->b_raw, (size_t)m * E * elem_size(c->dtype));
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->b_raw.p, a_host, (size_t)m * E * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
+  if (c->dtype == KMVP_F64)
+    hipLaunchKernelGGL((cg_widen_kernel<double>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
+                       (const double*)c->b_raw.p, w.r, m * E);
+  else
+    hipLaunchKernelGGL((cg_widen_kernel<float>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
+                       (const float*)c->b_raw.p, w.r, m * E);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(w.p, w.r, vec, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(w.x, 0, vec, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = cg_dots(c, w.r, w.r, m, E, w, hp, rs))) return rc;
+  anorm2 = rs;
+
+  auto worst = [&](const std::vector<double>& r2) {
+    double wv = 0.0;
+    for (int e = 0; e < E; ++e)
+      wv = std::max(wv, anorm2[e] > 0 ? std::sqrt(r2[e] / anorm2[e]) : 0.0);
+    return wv;
+  };
+
+  int it = 0;
+  double rel = worst(rs);
+  while (it < maxit && rel > rtol) {
+    if ((rc = cg_apply(c, kernel, w.p, m, E))) return rc;
+    const double* Ap = (const double*)c->out.p;
+    if ((rc = cg_dots(c, w.p, Ap, m, E, w, hp, pap))) return rc;
+    for (int e = 0; e < E; ++e) coef[e] = (pap[e] != 0.0 && rs[e] > 0.0) ? rs[e] / pap[e] : 0.0;
+    if ((rc = cg_axpy(c, w.x, w.x, w.p, coef, m, E, w))) return rc;
+    for (int e = 0; e < E; ++e) coef[e] = -coef[e];
+    if ((rc = cg_axpy(c, w.r, w.r, Ap, coef, m, E, w))) return rc;
+    if ((rc = cg_dots(c, w.r, w.r, m, E, w, hp, rs_new))) return rc;
+    for (int e = 0; e < E; ++e) coef[e] = rs[e] > 0.0 ? rs_new[e] / rs[e] : 0.0;
+    if ((rc = cg_axpy(c, w.p, w.r, w.p, coef, m, E, w))) return rc;
+    rs = rs_new;
+    rel = worst(rs);
+    ++it;
+  }
+
+  // true residual ||a - K x|| / ||a|| with one more product
+  if ((rc = cg_apply(c, kernel, w.x, m, E))) return rc;
+  // w.p = a (widened again) - K x
+  HIP_TRY(c, hipMemcpyAsync(c->b_raw.p, a_host, (size_t)m * E * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
+  if (c->dtype == KMVP_F64)
+    hipLaunchKernelGGL((cg_widen_kernel<double>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
+                       (const double*)c->b_raw.p, w.p, m * E);
+  else
+    hipLaunchKernelGGL((cg_widen_kernel<float>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
+                       (const float*)c->b_raw.p, w.p, m * E);
+  HIP_TRY(c, hipGetLastError());
+  for (int e = 0; e < E; ++e) coef[e] = -1.0;
+  if ((rc = cg_axpy(c, w.p, w.p, (const double*)c->out.p, coef, m, E, w))) return rc;
+  if ((rc = cg_dots(c, w.p, w.p, m, E, w, hp, rs_new))) return rc;
+  const double true_rel = worst(rs_new);
+
+  HIP_TRY(c, hipMemcpyAsync(out_b, w.x, vec, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_signal = false;  // b_raw was used as scratch
+  if (iters) *iters = it;
+  if (resid) *resid = true_rel;
+  if (true_rel > rtol * 1.5 && rel > rtol) {
+    c->err = "conjugate gradients reached maxit before the requested residual";
+    return KMVP_E_NOT_CONVERGED;
+  }
+  return KMVP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------
+// MINRES (Paige & Saunders) for the symmetric INDEFINITE inverse-distance systems (zero
+// diagonal), where conjugate gradients does not apply.  One product per iteration.
+
+// out[i][e] = ca[e] * a[i][e] + cb[e] * b[i][e] + cc[e] * c[i][e]   (coefficients: [3][E])
+__global__ void vec_lin3_kernel(double* __restrict__ out, const double* __restrict__ a,
+                                const double* __restrict__ b, const double* __restrict__ c,
+                                const double* __restrict__ coef, int64_t m, int E) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * E) return;
+  const int e = (int)(q % E);
+  double v = coef[e] * a[q];
+  if (b) v += coef[E + e] * b[q];
+  if (c) v += coef[2 * E + e] * c[q];
+  out[q] = v;
+}
+
+int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, int maxit,
+                 double* out_b, int* iters, double* resid) {
+  if (!c) return KMVP_E_INVALID;
+  if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
+  if (!c->same_points) return fail(c, KMVP_E_INVALID, "the solver needs x == y (pass x_or_null = NULL)");
+  if (c->world > 1) return fail(c, KMVP_E_UNSUPPORTED, "the solver is single-GPU in this build");
+  if (!a_host || !out_b || E < 1 || maxit < 0 || !(rtol > 0)) return fail(c, KMVP_E_INVALID, "bad solver arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t m = c->M;
+  const size_t n = (size_t)m * E;
+  const size_t vec = n * sizeof(double);
+  int rc = ensure(c, c->scratch, 8 * vec + sizeof(double) * ((CG_BLOCKS + 3) * (size_t)E));
+  if (rc) return rc;
+  double* base = (double*)c->scratch.p;
+  double *x = base, *r1 = base + n, *r2 = base + 2 * n, *y = base + 3 * n, *v = base + 4 * n;
+  double *w = base + 5 * n, *w1 = base + 6 * n, *w2 = base + 7 * n;
+  CgWork wk;
+  wk.x = wk.r = wk.p = nullptr;
+  wk.partial = base + 8 * n;
+  wk.coef = wk.partial + (size_t)CG_BLOCKS * E;  // 3*E coefficients
+  std::vector<double> hp((size_t)CG_BLOCKS * E), dots, coef(3 * (size_t)E);
+  auto lin3 = [&](double* out, const double* pa, const double* pb, const double* pc) -> int {
+    HIP_TRY(c, hipMemcpyAsync(wk.coef, coef.data(), sizeof(double) * 3 * E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(vec_lin3_kernel, dim3(blocks_for((int64_t)n)), dim3(256), 0, c->stream, out, pa, pb, pc,
+                       wk.coef, m, E);
+    HIP_TRY(c, hipGetLastError());
+    return KMVP_OK;
+  };
+
+  // r1 = r2 = y = a (widened), x = w = w2 = 0
+  rc = ensure(c, c->b_raw, n * elem_size(c->dtype));
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->b_raw.p, a_host, n * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
+  if (c->dtype == KMVP_F64)
+    hipLaunchKernelGGL((cg_widen_kernel<double>), dim3(blocks_for((int64_t)n)), dim3(256), 0, c->stream,
+                       (const double*)c->b_raw.p, y, (int64_t)n);
+  else
+    hipLaunchKernelGGL((cg_widen_kernel<float>), dim3(blocks_for((int64_t)n)), dim3(256), 0, c->stream,
+                       (const float*)c->b_raw.p, y, (int64_t)n);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(r1, y, vec, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(r2, y, vec, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(x, 0, vec, c->stream));
+  HIP_TRY(c, hipMemsetAsync(w, 0, vec, c->stream));
+  HIP_TRY(c, hipMemsetAsync(w2, 0, vec, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = cg_dots(c, y, y, m, E, wk, hp, dots))) return rc;
+
+  std::vector<double> beta1(E), beta(E), oldb(E, 0.0), dbar(E, 0.0), epsln(E, 0.0), phibar(E), cs(E, -1.0),
+      sn(E, 0.0), alfa(E), oldeps(E), delta(E), gbar(E), gamma(E), phi(E);
+  std::vector<char> done(E, 0);
+  for (int e = 0; e < E; ++e) {
+    beta1[e] = std::sqrt(dots[e]);
+    beta[e] = beta1[e];
+    phibar[e] = beta1[e];
+    if (!(beta1[e] > 0.0)) done[e] = 1;  // zero right-hand side: x = 0
+  }
+  auto worst = [&]() {
+    double wv = 0.0;
+    for (int e = 0; e < E; ++e)
+      if (beta1[e] > 0.0) wv = std::max(wv, phibar[e] / beta1[e]);
+    return wv;
+  };
+
+  int it = 0;
+  double rel = worst();
+  while (it < maxit && rel > rtol) {
+    ++it;
+    // v = y / beta
+    for (int e = 0; e < E; ++e) coef[e] = (!done[e] && beta[e] > 0.0) ? 1.0 / beta[e] : 0.0;
+    if ((rc = lin3(v, y, nullptr, nullptr))) return rc;
+    // y = K v - (beta / oldb) r1
+    if ((rc = cg_apply(c, kernel, v, m, E))) return rc;
+    for (int e = 0; e < E; ++e) {
+      coef[e] = 1.0;
+      coef[E + e] = (it >= 2 && oldb[e] > 0.0) ? -beta[e] / oldb[e] : 0.0;
+    }
+    if ((rc = lin3(y, (const double*)c->out.p, r1, nullptr))) return rc;
+    if ((rc = cg_dots(c, v, y, m, E, wk, hp, dots))) return rc;
+    for (int e = 0; e < E; ++e) alfa[e] = dots[e];
+    // y = y - (alfa / beta) r2 ; then r1 <- r2, r2 <- y (buffer rotation)
+    for (int e = 0; e < E; ++e) {
+      coef[e] = 1.0;
+      coef[E + e] = beta[e] > 0.0 ? -alfa[e] / beta[e] : 0.0;
+    }
+    if ((rc = lin3(r1, y, r2, nullptr))) return rc;  // written into the old r1 buffer
+    {
+      double* newy = r1;
+      r1 = r2;
+      r2 = newy;
+      // y must alias r2's content for the next iteration's "v = y / beta": keep y as its own buffer
+      HIP_TRY(c, hipMemcpyAsync(y, r2, vec, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if ((rc = cg_dots(c, r2, r2, m, E, wk, hp, dots))) return rc;
+    for (int e = 0; e < E; ++e) {
+      oldb[e] = beta[e];
+      beta[e] = std::sqrt(std::max(dots[e], 0.0));
+      oldeps[e] = epsln[e];
+      delta[e] = cs[e] * dbar[e] + sn[e] * alfa[e];
+      gbar[e] = sn[e] * dbar[e] - cs[e] * alfa[e];
+      epsln[e] = sn[e] * beta[e];
+      dbar[e] = -cs[e] * beta[e];
+      gamma[e] = std::max(std::sqrt(gbar[e] * gbar[e] + beta[e] * beta[e]), 1e-300);
+      cs[e] = gbar[e] / gamma[e];
+      sn[e] = beta[e] / gamma[e];
+      phi[e] = cs[e] * phibar[e];
+      phibar[e] = sn[e] * phibar[e];
+    }
+    // w_new = (v - oldeps w1 - delta w2) / gamma with w1 <- w2, w2 <- w
+    {
+      double* t = w1;
+      w1 = w2;
+      w2 = w;
+      w = t;
+    }
+    for (int e = 0; e < E; ++e) {
+      const double dn = done[e] ? 0.0 : 1.0 / gamma[e];
+      coef[e] = dn;
+      coef[E + e] = -oldeps[e] * dn;
+      coef[2 * E + e] = -delta[e] * dn;
+    }
+    if ((rc = lin3(w, v, w1, w2))) return rc;
+    // x = x + phi w
+    for (int e = 0; e < E; ++e) {
+      coef[e] = 1.0;
+      coef[E + e] = done[e] ? 0.0 : phi[e];
+    }
+    if ((rc = lin3(x, x, w, nullptr))) return rc;
+    for (int e = 0; e < E; ++e)
+      if (!done[e] && (phibar[e] <= rtol * beta1[e] || beta[e] == 0.0)) done[e] = 1;
+    rel = worst();
+  }
+
+  // true residual ||a - K x|| / ||a||
+  if ((rc = cg_apply(c, kernel, x, m, E))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->b_raw.p, a_host, n * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
+  if (c->dtype == KMVP_F64)
+    hipLaunchKernelGGL((cg_widen_kernel<double>), dim3(blocks_for((int64_t)n)), dim3(256), 0, c->stream,
+                       (const double*)c->b_raw.p, v, (int64_t)n);
+  else
+    hipLaunchKernelGGL((cg_widen_kernel<float>), dim3(blocks_for((int64_t)n)), dim3(256), 0, c->stream,
+                       (const float*)c->b_raw.p, v, (int64_t)n);
+  HIP_TRY(c, hipGetLastError());
+  for (int e = 0; e < E; ++e) {
+    coef[e] = 1.0;
+    coef[E + e] = -1.0;
+  }
+  if ((rc = lin3(v, v, (const double*)c->out.p, nullptr))) return rc;
+  if ((rc = cg_dots(c, v, v, m, E, wk, hp, dots))) return rc;
+  double true_rel = 0.0;
+  for (int e = 0; e < E; ++e)
+    if (beta1[e] > 0.0) true_rel = std::max(true_rel, std::sqrt(dots[e]) / beta1[e]);
+
+  HIP_TRY(c, hipMemcpyAsync(out_b, x, vec, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_signal = false;
+  if (iters) *iters = it;
+  if (resid) *resid = true_rel;
+  if (true_rel > rtol * 1.5 && rel > rtol) {
+    c->err = "MINRES reached maxit before the requested residual";
+    return KMVP_E_NOT_CONVERGED;
+  }
+  return KMVP_OK;
+}
+
+}  // namespace kmvp
