@@ -44,6 +44,8 @@ FLOPS_PER_PAIR = {"gaussian": 12, "inverse-distance": 12, "absolute-exponential"
 SLOTS_PER_PAIR = {
     "lowd_kernel": {"gaussian": 11, "inverse-distance": 11, "absolute-exponential": 15},
     "fast_kernel": {"gaussian": 5, "inverse-distance": 5, "absolute-exponential": 9},
+    # centred form: + ~0.7 operand rebuild + ~0.6 closest-pair test per pair
+    "cfast_kernel": {"gaussian": 6.3, "inverse-distance": 6.3, "absolute-exponential": 10.3},
 }
 MFMA_FLOPS_PER_PAIR_FAST = 2 * 32  # two 32x32x16 bf16 k-steps (K = 6 D + 6 = 24 -> 32) for D = 3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
@@ -160,7 +162,7 @@ def main():
     kname = algo.device_kernel
     # the other squared-distance form on the same resident data, for the record (3 steps, untimed region)
     other = None
-    if args.sqdists == "auto" and kname == "fast_kernel" and world == 1:
+    if args.sqdists == "auto" and kname in ("fast_kernel", "cfast_kernel") and world == 1:
         algo.set_query_arguments(fast_sqdists=0)
         algo.query()
         oms = []
@@ -234,7 +236,7 @@ def main():
                 "issue_frac": SLOTS_PER_PAIR.get(kname, SLOTS_PER_PAIR["lowd_kernel"])[kernel] * shard_pairs
                               / (k_ms * 1e-3) / PEAK_ISSUE_SLOTS,
                 "mfma_frac": (MFMA_FLOPS_PER_PAIR_FAST * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
-                              if kname == "fast_kernel" else 0.0),
+                              if kname in ("fast_kernel", "cfast_kernel") else 0.0),
                 # north-star's "HBM" reading: bytes every wavefront streams from the source block
                 "source_stream_GBps": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4 / (k_ms * 1e-3) / 1e9,
                 "source_stream_frac_of_hbm_peak": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4
@@ -244,6 +246,8 @@ def main():
         }
         out["config"]["sqdists"] = ("expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "
                                     "(reference fast_sqdists=True form)" if kname == "fast_kernel"
+                                    else "expanded around per-group centres of Morton-sorted sources on the bf16 matrix "
+                                         "cores, closest pairs recomputed exactly" if kname == "cfast_kernel"
                                     else "difference form (reference fast_sqdists=False)")
         if other is not None:
             out["difference_form"] = other

@@ -135,9 +135,15 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  *   "chunk"            sources summed in fp32 before folding into the fp64 sum
  *   "fast_sqdists"     squared distances in the expanded form |x|^2+|y|^2-2x.y on the matrix
  *                      cores (bruteforce.py:36-49 `fast_sqdists`; float32, D <= 7, E == 1):
- *                      1 = always, 0 = never (difference form, bruteforce.py:53-54),
- *                      -1 = auto (default): only where it is as accurate as the difference
- *                      form -- the Gaussian kernel on clouds of small scaled radius
+ *                      1 = always, around one centre for the whole cloud (fast_kernel);
+ *                      2 = always, around per-group centres of Morton-sorted sources with exact
+ *                          recomputation of the closest pairs (cfast_kernel, D <= 4);
+ *                      0 = never (difference form, bruteforce.py:53-54);
+ *                      -1 = auto (default): the cheapest form that is as accurate as the
+ *                          difference form -- 1 for the Gaussian on clouds of small scaled
+ *                          radius, else 2 where it applies
+ *   "same_points_global" 1 when the targets passed to kmvp_set_points are the unsharded
+ *                      sources (sharded same_points): enables form 2 for inverse-distance
  *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4 */
 int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);
 

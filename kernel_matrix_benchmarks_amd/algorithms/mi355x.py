@@ -49,15 +49,19 @@ class MI355XProduct(BaseProduct):
         self.device = device
         self.comm = comm
         # fast_sqdists mirrors the reference's flag (bruteforce.py:70,36-49): True = expanded
-        # |x|^2+|y|^2-2x.y form (here on the matrix cores), False = difference form; None lets
-        # the library use the expanded form only where it is equally accurate.
+        # |x|^2+|y|^2-2x.y form around one centre (matrix cores), False = difference form,
+        # "centred" = expanded around per-group centres with exact recomputation of the closest
+        # pairs; None lets the library pick the cheapest form that is as accurate as the
+        # difference form.
+        if fast_sqdists not in (None, False, True, "centred"):
+            raise ValueError("fast_sqdists must be None, False, True or 'centred'")
         self.fast_sqdists = fast_sqdists
         self._options = dict(targets_per_lane=targets_per_lane, feed=feed, segments=segments,
                              chunk=chunk, fast_tiles=fast_tiles)
         self._ctx = None
         self.res = None
         self.name = f"MI355XProduct({_precision_name(precision)})" if fast_sqdists is None else (
-            f"MI355XProduct({_precision_name(precision)}, fast_sqdists={bool(fast_sqdists)})")
+            f"MI355XProduct({_precision_name(precision)}, fast_sqdists={fast_sqdists})")
 
     # -- untimed -------------------------------------------------------------------
     def prepare_data(self, *, source_points, target_points, same_points=False,
@@ -79,13 +83,16 @@ class MI355XProduct(BaseProduct):
                 if value:
                     self._ctx.set_option(key, value)
             if self.fast_sqdists is not None:
-                self._ctx.set_option("fast_sqdists", 1 if self.fast_sqdists else 0)
+                self._ctx.set_option("fast_sqdists", 2 if self.fast_sqdists == "centred" else int(bool(self.fast_sqdists)))
         world = 1 if self.comm is None else self.comm.world
         if world > 1:
             # every rank keeps all targets and one contiguous slice of the sources
             self._shard = sharding.shard_range(self.M, self.comm.rank, world)
             lo, hi = self._shard
             self.comm.attach(self._ctx)
+            # the context sees the targets as an explicit array; tell it when they ARE the
+            # (unsharded) sources, which the inverse-distance zero rule of the centred form needs
+            self._ctx.set_option("same_points_global", 1 if x is None else 0)
             self._ctx.set_points(np.ascontiguousarray(y[lo:hi]), y if x is None else x,
                                  self._dtype_code, j_offset=lo, M_total=self.M)
         else:

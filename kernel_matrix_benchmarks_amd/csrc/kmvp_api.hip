@@ -89,7 +89,7 @@ void kmvp_destroy(kmvp_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled, &c->y_scaled,
-                    &c->part, &c->partd, &c->aux, &c->sums, &c->out, &c->scratch})
+                    &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch})
     release(*b);
   for (int i = 0; i < 3; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -232,8 +232,10 @@ int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
     if (value < 0 || value > 65535) return fail(c, KMVP_E_INVALID, "segments out of range");
     c->opt_segments = (int)value;
   } else if (k == "fast_sqdists") {
-    if (value < -1 || value > 1) return fail(c, KMVP_E_INVALID, "fast_sqdists must be -1 (auto), 0 or 1");
+    if (value < -1 || value > 2) return fail(c, KMVP_E_INVALID, "fast_sqdists must be -1 (auto), 0, 1 or 2");
     c->opt_fast = (int)value;
+  } else if (k == "same_points_global") {
+    c->opt_same_global = value != 0;
   } else if (k == "fast_tiles") {
     if (value != 0 && value != 1 && value != 2 && value != 4)
       return fail(c, KMVP_E_INVALID, "fast_tiles must be 0 (auto), 1, 2 or 4");
@@ -251,7 +253,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
   if (!c) return 0;
   size_t t = 0;
   for (const DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled,
-                          &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sums, &c->out, &c->scratch})
+                          &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch})
     t += b->cap;
   return (int64_t)t;
 }

@@ -22,7 +22,7 @@
 namespace kmvp {
 
 // which path's layouts the shared xs / rec buffers hold
-enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2 };
+enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2, LAYOUT_CFAST = 3 };
 
 struct DevBuf {
   void* p = nullptr;
@@ -103,7 +103,8 @@ struct kmvp_ctx {
   DevBuf y_raw, x_raw, b_raw;   // caller's arrays in the working precision
   DevBuf xs, rec;               // kernel layouts (specialised path; bf16 path: augmented targets, tile images)
   DevBuf partd;                 // bf16 path: partial denominators
-  DevBuf aux;                   // fast path: |x'|^2 per target + cloud centre
+  DevBuf aux;                   // cloud centre, squared radius, half-widths (fast_center_kernel)
+  DevBuf sortbuf, perm;         // centred path: radix-sort scratch, Morton order of the sources
   DevBuf x_scaled, y_scaled;    // scaled copies (generic path)
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
   DevBuf scratch;               // CG vectors / dot products
@@ -119,7 +120,9 @@ struct kmvp_ctx {
 
   // tuning (kmvp_set_option)
   int opt_feed = -1, opt_T = 0, opt_segments = 0, opt_chunk = 512;
-  int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always
+  int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always, 2 always the centred form
+  int opt_same_global = 0;                // the targets ARE the (unsharded) sources although x was passed explicitly
+  uint64_t perm_ver = 0;                  // points version the Morton order belongs to
   float cloud_radius2 = INFINITY;          // squared half-diagonal of the clouds' bounding box
   uint64_t centre_ver = 0;
 

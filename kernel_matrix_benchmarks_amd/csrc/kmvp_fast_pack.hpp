@@ -6,7 +6,7 @@
 namespace kmvp {
 
 // centre[d] = midpoint of the bounding box of both clouds, centre[8] = squared half-diagonal
-// of that box (one workgroup; runs once per kmvp_set_points).  Subtracting the centre before
+// of that box, centre[9 + d] = half-width along d (one workgroup; runs once per kmvp_set_points).  Subtracting the centre before
 // the |x|^2 + |y|^2 - 2x.y expansion keeps the cancellation error of the fast form as small
 // as the data allow; the half-diagonal bounds |x'|^2, |y'|^2 and drives the "auto" choice.
 __global__ void fast_center_kernel(const float* __restrict__ y, int64_t m, const float* __restrict__ x,
@@ -42,6 +42,7 @@ __global__ void fast_center_kernel(const float* __restrict__ y, int64_t m, const
       centre[d] = ok ? c : 0.f;
       const float half = ok ? 0.5f * (hi[0] - lo[0]) : INFINITY;
       radius2 += half * half;
+      centre[9 + d] = half;
     }
     __syncthreads();
   }

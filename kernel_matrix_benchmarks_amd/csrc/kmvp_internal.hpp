@@ -66,4 +66,19 @@ hipError_t launch_fast_absexp(int KS, int sig, int TT, const FastArgs& args, dim
 hipError_t launch_fast_invdist(int KS, int sig, int TT, const FastArgs& args, dim3 grid,
                                hipStream_t stream, const char** kernel_name);
 
+
+// centred split-bf16 MFMA path (kmvp_cfast.hpp): D <= 4, E == 1, every kernel
+constexpr int CFAST_MAX_D = 4;
+constexpr int CFAST_DEFAULT_TT = 2;
+struct CfastArgs;
+hipError_t launch_cfast_gaussian(int sig, int TT, const CfastArgs& args, dim3 grid, hipStream_t stream,
+                                 const char** kernel_name);
+hipError_t launch_cfast_absexp(int sig, int TT, const CfastArgs& args, dim3 grid, hipStream_t stream,
+                               const char** kernel_name);
+hipError_t launch_cfast_invdist(int sig, int TT, const CfastArgs& args, dim3 grid, hipStream_t stream,
+                                const char** kernel_name);
+// kmvp_sort.hip: hipcub radix sort of (key, value) pairs; tmp == nullptr queries the scratch size
+hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const unsigned* keys_in, unsigned* keys_out,
+                          const int* vals_in, int* vals_out, int64_t n, hipStream_t stream);
+
 }  // namespace kmvp

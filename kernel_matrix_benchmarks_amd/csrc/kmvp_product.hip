@@ -3,6 +3,7 @@
 //   segment reduction -> [RCCL all-reduce over the source shards] -> normalise.
 // Reference call this serves: BruteForceProductBLAS.query (bruteforce.py:130-153).
 #include "kmvp_ctx.hpp"
+#include "kmvp_cfast_pack.hpp"
 #include "kmvp_fast_pack.hpp"
 #include "kmvp_mfma_pack.hpp"
 
@@ -360,6 +361,103 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   return finish_product(c, count, N, n_pad, E, sig);
 }
 
+// centred split-bf16 MFMA path (kmvp_cfast.hpp): float32, D <= 4, E == 1, every kernel.
+int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D;
+  const int E = 1;
+  const int NE = sig == SIG_NORM ? 2 : 1;
+  const int EB = sig == SIG_DENSITY ? 0 : 1;
+  const int64_t N = c->N, M = c->M;
+  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : CFAST_DEFAULT_TT;
+  const float scale = scale_for<float>(kernel);
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int64_t tile = (int64_t)32 * TT * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(N, tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t per_stage = (int64_t)CF_GROUP * CF_STAGE_GROUPS;
+  const int64_t m_stages = (M + per_stage - 1) / per_stage;
+  const int64_t m_alloc = m_stages * per_stage;
+  if (c->m_total > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "more than 2^31 sources");
+  int rc;
+
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, CF_STAGE_BYTES, 4);
+  const int64_t seg_stages = (m_stages + segments - 1) / segments;
+  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+
+  const float* centre = (const float*)c->aux.p;  // written by measure_clouds()
+  if (c->perm_ver != c->points_ver) {
+    // Morton order of the sources (independent of the kernel): keys -> radix sort -> perm
+    if ((rc = ensure(c, c->perm, (size_t)m_alloc * sizeof(int)))) return rc;
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, m_alloc, c->stream));
+    const size_t keys_bytes = (size_t)m_alloc * sizeof(unsigned);
+    if ((rc = ensure(c, c->sortbuf, 3 * keys_bytes + tmp_bytes + 256))) return rc;
+    unsigned* keys_in = (unsigned*)c->sortbuf.p;
+    unsigned* keys_out = keys_in + m_alloc;
+    int* vals_in = (int*)(keys_out + m_alloc);
+    void* tmp = (void*)((((uintptr_t)(vals_in + m_alloc)) + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(cfast_morton_kernel, dim3(blocks_for(m_alloc)), dim3(256), 0, c->stream,
+                       (const float*)c->y_raw.p, centre, keys_in, vals_in, M, m_alloc, D);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, sort_pairs_u32(tmp, &tmp_bytes, keys_in, keys_out, vals_in, (int*)c->perm.p, m_alloc, c->stream));
+    c->perm_ver = c->points_ver;
+    c->packed_layout = -1;  // force a re-pack below
+  }
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                         c->packed_layout != LAYOUT_CFAST || c->packed_T != TT;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * 4 * sizeof(float)))) return rc;
+    hipLaunchKernelGGL(pack_cfast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
+                       centre, (float*)c->xs.p, N, n_pad, D, scale);
+  }
+  if (sig_stale) {
+    if ((rc = ensure(c, c->rec, (size_t)m_stages * CF_STAGE_BYTES))) return rc;
+    hipLaunchKernelGGL(pack_cfast_sources_kernel, dim3((unsigned)(m_alloc / CF_GROUP)), dim3(CF_GROUP), 0,
+                       c->stream, (const float*)c->y_raw.p, (const float*)c->b_raw.p, (const int*)c->perm.p,
+                       centre, (unsigned char*)c->rec.p, M, D, EB, scale, c->j_offset);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = kernel;
+  c->packed_sig = sig;
+  c->packed_layout = LAYOUT_CFAST;
+  c->packed_T = TT;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
+  CfastArgs a;
+  a.xraw = (const float*)c->xs.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.part = (double*)c->part.p;
+  a.n_pad = n_pad;
+  a.m_stages = m_stages;
+  a.seg_stages = seg_stages;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.chunk_stages = std::max<int>(1, c->opt_chunk / (int)per_stage);
+  a.j_offset = c->j_offset;
+  a.m_total = c->m_total;
+  const dim3 grid((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  hipError_t le;
+  switch (kernel) {
+    case K_GAUSSIAN: le = launch_cfast_gaussian(sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_cfast_absexp(sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_cfast_invdist(sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+  }
+  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
+  HIP_TRY(c, le);
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+  const int64_t count = (int64_t)NE * n_pad;
+  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->sums.p, count, segments);
+  HIP_TRY(c, hipGetLastError());
+  return finish_product(c, count, N, n_pad, E, sig);
+}
+
 // bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
 // to augmented bf16 rows / LDS tile images, sums come back as fp32 partials.
 int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
@@ -458,7 +556,7 @@ int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D) {
   c->cloud_radius2 = INFINITY;
   if (dtype != KMVP_F32 || D > FAST_MAX_D || M <= 0 || N <= 0) return KMVP_OK;
   int rc;
-  if ((rc = ensure(c, c->aux, 16 * sizeof(float)))) return rc;
+  if ((rc = ensure(c, c->aux, 32 * sizeof(float)))) return rc;
   hipLaunchKernelGGL(fast_center_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)c->y_raw.p, M,
                      c->same_points ? (const float*)nullptr : (const float*)c->x_raw.p, N, D,
                      (float*)c->aux.p);
@@ -506,14 +604,21 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
   if (c->dtype == KMVP_F32 && c->D <= FAST_MAX_D && (c->density || c->E == 1) && c->centre_ver == c->points_ver) {
-    // "fast_sqdists": expanded squared distances on the matrix cores.  auto = only where the
-    // expansion is as accurate as the difference form to working precision: the Gaussian
-    // (smooth in s; exp(-sqrt(s)) and 1/sqrt(s) amplify the absolute error of s near
-    // coincident points, as they do in the reference's own fast form) on clouds whose scaled
-    // radius keeps eps32 * (|x'|^2 + |y'|^2) ~ 1e-6.
+    // "fast_sqdists": squared distances in the expanded form on the matrix cores.
+    //   fast_kernel  one centre for the whole cloud: absolute error eps32 (|x'|^2 + |y'|^2) in s
+    //                -> as accurate as the difference form only for the Gaussian (smooth in s)
+    //                on clouds of small scaled radius;
+    //   cfast_kernel centre per source group + exact recomputation of the closest pairs:
+    //                relative accuracy in s -> every kernel, any radius (D <= 4).  The
+    //                inverse-distance zero rule is applied there to coincident pairs only, so
+    //                it needs targets == sources.
+    // auto (-1) picks the cheapest form that is as accurate as the difference form.
     const float sc = scale_for<float>(kernel);
-    const bool accurate = kernel == K_GAUSSIAN && c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
-    if (c->opt_fast == 1 || (c->opt_fast < 0 && accurate)) return run_product_fast(c, kernel, sig);
+    const bool global_ok = kernel == K_GAUSSIAN && c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
+    const bool same = c->same_points || c->opt_same_global;
+    const bool centred_ok = c->D <= CFAST_MAX_D && (kernel != K_INVDIST || (same && c->N == c->m_total));
+    if (c->opt_fast == 1 || (c->opt_fast < 0 && global_ok)) return run_product_fast(c, kernel, sig);
+    if (centred_ok && (c->opt_fast == 2 || c->opt_fast < 0)) return run_product_cfast(c, kernel, sig);
   }
   if (c->dtype == KMVP_F64) return run_product_t<double>(c, kernel, sig);
   return run_product_t<float>(c, kernel, sig);

@@ -103,15 +103,42 @@ def test_fast_sqdists_matches_reference(case, expected):
     assert rel_err(got, truth) <= tol, (rel_err(got, truth), tol)
 
 
+CENTRED = [c for c in CASES if c["D"] <= 4 and (c["E"] == 1 or c["density_estimation"])
+           and (c["kernel"] != "inverse-distance" or c["same_points"])]
+
+
+@pytest.mark.parametrize("case", CENTRED, ids=[c["name"] for c in CENTRED])
+def test_centred_sqdists_matches_reference(case, expected):
+    """fast_sqdists="centred": expansion around the centre of each group of Morton-sorted sources
+    plus exact recomputation of the closest pairs -- held to the tolerance of the difference form
+    for EVERY kernel, non-finite rows (coincident points) included."""
+    y, x, b = golden_cases.make_inputs(case)
+    truth = expected[f"{case['name']}/f64"]
+    ref32 = expected[f"{case['name']}/f32"].astype(np.float64)
+    got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists="centred")
+    if not (case["normalize_rows"] and case["density_estimation"]):
+        assert extra["device_kernel"] == "cfast_kernel"
+    assert np.array_equal(row_finite(got), row_finite(truth)), "non-finite rows differ"
+    tol = max(TOL32, 2 * rel_err(ref32, truth))
+    assert rel_err(got, truth) <= tol, (rel_err(got, truth), tol)
+
+
 def test_fast_sqdists_auto_policy():
     """auto: unit-cube gaussian -> matrix cores; same cloud blown up 100x, or 1/r -> difference form."""
     y, b = kmvp_oracle.uniform_cube(2000, 3)
     _, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32")
     assert extra["device_kernel"] == "fast_kernel"
     _, extra = run_plugin(dict(kernel="gaussian", D=3), 100 * y + 1e4, None, b, "float32")
-    assert extra["device_kernel"] == "lowd_kernel"
+    assert extra["device_kernel"] == "cfast_kernel"  # large scaled radius: per-group centres
     _, extra = run_plugin(dict(kernel="inverse-distance", D=3), y, None, b, "float32")
-    assert extra["device_kernel"] == "lowd_kernel"
+    assert extra["device_kernel"] == "cfast_kernel"  # same points: zero rule = coincident pairs
+    _, extra = run_plugin(dict(kernel="inverse-distance", D=3), y, y[:1500] + 0.5, b, "float32")
+    assert extra["device_kernel"] == "lowd_kernel"   # index-based zero rule on distinct points
+    _, extra = run_plugin(dict(kernel="absolute-exponential", D=3), y, None, b, "float32")
+    assert extra["device_kernel"] == "cfast_kernel"
+    y5 = np.random.RandomState(0).rand(500, 5)
+    _, extra = run_plugin(dict(kernel="absolute-exponential", D=5), y5, None, b[:500], "float32")
+    assert extra["device_kernel"] == "lowd_kernel"   # D > 4
     _, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32", fast_sqdists=False)
     assert extra["device_kernel"] == "lowd_kernel"
     got, extra = run_plugin(dict(kernel="gaussian", D=3), y + 1e3, None, b, "float32")  # far from the origin
@@ -311,10 +338,12 @@ def test_inverse_distance_1e6_row_subset_with_sharded_offsets():
     for lo, hi in ((0, n // 2 + 7), (n // 2 + 7, n)):
         ctx = _lib.Context(0)
         try:
+            ctx.set_option("same_points_global", 1)  # what the plugin sets for sharded same_points
             ctx.set_points(np.ascontiguousarray(y[lo:hi], dtype=np.float32), y.astype(np.float32),
                            _lib.KMVP_F32, j_offset=lo, M_total=n)
             ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
             ctx.run("inverse-distance", False)
+            assert ctx.last_kernel_name == "cfast_kernel"
             total += ctx.get_result(n, 1)
         finally:
             ctx.close()
