@@ -35,18 +35,21 @@ if "4" in which:
     rs = np.random.RandomState(n + 3)
     y = rs.rand(n, 3); b = rs.randn(n, 1)
     lo, hi = 0, n // 8  # the shard of rank 0 of 8
-    ctx = _lib.Context(0)
-    ctx.set_points(np.ascontiguousarray(y[lo:hi], dtype=np.float32), y.astype(np.float32), _lib.KMVP_F32, j_offset=lo, M_total=n)
-    ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
-    ctx.run("inverse-distance", False)
-    t0 = time.perf_counter(); ctx.run("inverse-distance", False); wall = time.perf_counter() - t0
-    part = ctx.get_result(n, 1)
     rows = np.random.RandomState(1).choice(n, 64, replace=False)
     want, _ = c_oracle.product(kernel="inverse-distance", source_points=y[lo:hi], target_points=y, source_signal=b[lo:hi], rows=rows, j_offset=lo, M_total=n, raw_sums=True)
-    err = np.max(np.abs(part[rows] - want)) / np.max(np.abs(want))
-    print(f"config4 shard 1/8: N={n} x M={hi-lo} inverse-distance f32: wall {wall*1e3:.1f} ms kernel {ctx.last_kernel_ms:.1f} ms "
-          f"pairs/s {n*(hi-lo)/(ctx.last_kernel_ms*1e-3):.3e} finite {bool(np.isfinite(part).all())} rel_err {err:.2e} device_MB {ctx.device_bytes/1e6:.0f}", flush=True)
-    ctx.close()
+    for form, opt in (("difference form", 0), ("auto", -1)):
+        ctx = _lib.Context(0)
+        ctx.set_option("fast_sqdists", opt)
+        ctx.set_option("same_points_global", 1)  # the targets ARE the full source set (what the sharded plugin sets)
+        ctx.set_points(np.ascontiguousarray(y[lo:hi], dtype=np.float32), y.astype(np.float32), _lib.KMVP_F32, j_offset=lo, M_total=n)
+        ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
+        ctx.run("inverse-distance", False)
+        t0 = time.perf_counter(); ctx.run("inverse-distance", False); wall = time.perf_counter() - t0
+        part = ctx.get_result(n, 1)
+        err = np.max(np.abs(part[rows] - want)) / np.max(np.abs(want))
+        print(f"config4 shard 1/8 ({form} -> {ctx.last_kernel_name}): N={n} x M={hi-lo} inverse-distance f32: wall {wall*1e3:.1f} ms kernel {ctx.last_kernel_ms:.1f} ms "
+              f"pairs/s {n*(hi-lo)/(ctx.last_kernel_ms*1e-3):.3e} finite {bool(np.isfinite(part).all())} rel_err {err:.2e} device_MB {ctx.device_bytes/1e6:.0f}", flush=True)
+        ctx.close()
 
 if "5" in which:
     n = 100_000
