@@ -178,11 +178,12 @@ class MI355XSolver(BaseSolver):
     matrix (zero diagonal, bruteforce.py:13-14)."""
 
     def __init__(self, *, kernel, dimension, normalize_rows=False, precision=np.float64,
-                 device=0, rtol=1e-6, maxit=10000):
+                 device=0, rtol=1e-6, maxit=10000, comm=None):
         super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows,
                          precision=precision)
         if kernel not in SUPPORTED_KERNELS:
             raise NotImplementedError(f"MI355XSolver doesn't support kernel {kernel}.")
+        self.comm = comm  # sharding.Communicator: operator sharded over the sources, vectors replicated
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)
         if self._dtype_code == _lib.KMVP_BF16:
             raise NotImplementedError("MI355XSolver needs float32 or float64")
@@ -201,7 +202,18 @@ class MI355XSolver(BaseSolver):
         self.M, self.D = y.shape
         if self._ctx is None:
             self._ctx = _lib.Context(self.device)
-        self._ctx.set_points(y, None, self._dtype_code)
+        world = 1 if self.comm is None else self.comm.world
+        if world > 1:
+            # every rank iterates on the full (replicated) Krylov vectors; the operator
+            # is sharded over the sources and summed by the product's own all-reduce
+            self._shard = sharding.shard_range(self.M, self.comm.rank, world)
+            lo, hi = self._shard
+            self.comm.attach(self._ctx)
+            self._ctx.set_option("same_points_global", 1)
+            self._ctx.set_points(np.ascontiguousarray(y[lo:hi]), y, self._dtype_code, j_offset=lo, M_total=self.M)
+        else:
+            self._shard = (0, self.M)
+            self._ctx.set_points(y, None, self._dtype_code)
 
     def fit(self):
         """Nothing to factorise."""
@@ -225,7 +237,7 @@ class MI355XSolver(BaseSolver):
 
     def get_additional(self):
         return {"cg_iterations": self.iterations, "cg_relative_residual": self.residual,
-                "cg_converged": bool(self.converged)}
+                "cg_converged": bool(self.converged), "n_gpus": 1 if self.comm is None else self.comm.world}
 
     def done(self):
         if self._ctx is not None:

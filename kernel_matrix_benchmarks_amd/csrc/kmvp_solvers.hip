@@ -11,6 +11,20 @@ namespace kmvp {
 
 constexpr int CG_BLOCKS = 256;
 
+// The system matrix is K(y, y) on ALL points.  Single GPU: x == y (x_or_null = NULL).  Sharded:
+// every rank holds all points as targets and its slice of them as sources
+// (same_points_global, N == M_total), and a communicator is attached.
+static int solver_shape(kmvp_ctx* c) {
+  if (c->same_points && c->world == 1) return KMVP_OK;
+  if (c->world > 1 && !c->comm) return fail(c, KMVP_E_INVALID, "sharded solver without kmvp_comm_init");
+  const bool sharded_square = c->opt_same_global && c->N == c->m_total && c->j_offset + c->M <= c->m_total &&
+                             (c->world > 1 || c->M == c->m_total);  // one rank must hold every source
+  if (c->same_points && c->world > 1)
+    return fail(c, KMVP_E_INVALID, "sharded solver: pass all points as targets and this rank's slice as sources");
+  if (!sharded_square) return fail(c, KMVP_E_INVALID, "the solver needs x == y (pass x_or_null = NULL)");
+  return KMVP_OK;
+}
+
 // partial[block][e] = sum over the block's rows of u[i][e] * v[i][e]
 __global__ void cg_dot_kernel(const double* __restrict__ u, const double* __restrict__ v, int64_t m,
                               int E, double* __restrict__ partial) {
@@ -78,9 +92,16 @@ int cg_axpy(kmvp_ctx* c, double* out, const double* u, const double* v,
   return KMVP_OK;
 }
 
-// K applied to the device vector v (M,E) double; the result lands in c->out (M,E) double.
-int cg_apply(kmvp_ctx* c, int kernel, const double* v, int64_t m, int E) {
-  int rc = ensure(c, c->b_raw, (size_t)m * E * elem_size(c->dtype));
+// K applied to the device vector v (n,E) double, n = all points; the result lands in c->out
+// (n,E) double.  With source sharding the Krylov vectors are replicated on every
+// rank, the operator is sharded: this rank's signal is its own slice v[j_offset .. j_offset+M)
+// and run_product() ends with the all-reduce of the (n,E) sums, so every rank continues with
+// bitwise the same vectors.
+int cg_apply(kmvp_ctx* c, int kernel, const double* v, int64_t n, int E) {
+  const int64_t m = c->M;  // sources of this rank
+  (void)n;
+  v += (size_t)c->j_offset * E;
+  int rc = ensure(c, c->b_raw, (size_t)n * E * elem_size(c->dtype));  // also holds the right-hand side
   if (rc) return rc;
   if (c->dtype == KMVP_F64)
     hipLaunchKernelGGL((cg_cast_kernel<double>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream, v,
@@ -100,11 +121,10 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
              double* out_b, int* iters, double* resid) {
   if (!c) return KMVP_E_INVALID;
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
-  if (!c->same_points) return fail(c, KMVP_E_INVALID, "the solver needs x == y (pass x_or_null = NULL)");
-  if (c->world > 1) return fail(c, KMVP_E_UNSUPPORTED, "the solver is single-GPU in this build");
+  if (int rc0 = solver_shape(c)) return rc0;
   if (!a_host || !out_b || E < 1 || maxit < 0 || !(rtol > 0)) return fail(c, KMVP_E_INVALID, "bad solver arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  const int64_t m = c->M;
+  const int64_t m = c->N;  // length of the Krylov vectors: all points
   const size_t vec = (size_t)m * E * sizeof(double);
   int rc = ensure(c, c->scratch, 3 * vec + sizeof(double) * (CG_BLOCKS + 1) * E);
   if (rc) return rc;
@@ -208,11 +228,10 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
                  double* out_b, int* iters, double* resid) {
   if (!c) return KMVP_E_INVALID;
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
-  if (!c->same_points) return fail(c, KMVP_E_INVALID, "the solver needs x == y (pass x_or_null = NULL)");
-  if (c->world > 1) return fail(c, KMVP_E_UNSUPPORTED, "the solver is single-GPU in this build");
+  if (int rc0 = solver_shape(c)) return rc0;
   if (!a_host || !out_b || E < 1 || maxit < 0 || !(rtol > 0)) return fail(c, KMVP_E_INVALID, "bad solver arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  const int64_t m = c->M;
+  const int64_t m = c->N;  // length of the Krylov vectors: all points
   const size_t n = (size_t)m * E;
   const size_t vec = n * sizeof(double);
   int rc = ensure(c, c->scratch, 8 * vec + sizeof(double) * ((CG_BLOCKS + 3) * (size_t)E));

@@ -425,6 +425,42 @@ def test_cg_solver_config5_shape_small():
     assert np.linalg.norm(Kb - a[rows]) / np.linalg.norm(a[rows]) <= 5e-6
 
 
+def test_solver_in_the_sharded_shape_on_one_gpu():
+    """The multi-GPU solver hands every rank ALL points as targets and a slice as
+    sources, Krylov vectors replicated.  With one rank the slice is everything: same operator,
+    same iterates as the x == y form; a partial slice without a communicator must be refused."""
+    n = 3000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    a = kmvp_oracle.product(kernel="absolute-exponential", source_points=y, source_signal=b)
+    sols = []
+    for sharded_shape in (False, True):
+        ctx = _lib.Context(0)
+        try:
+            if sharded_shape:
+                ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+                ctx.set_option("same_points_global", 1)
+                ctx.set_points(y, y, _lib.KMVP_F64, j_offset=0, M_total=n)
+            else:
+                ctx.set_points(y, None, _lib.KMVP_F64)
+            sol, iters, resid, ok = ctx.cg_solve("absolute-exponential", a, 1e-9, 5000)
+        finally:
+            ctx.close()
+        assert ok and resid <= 2e-9, (sharded_shape, iters, resid)
+        sols.append((sol, iters))
+    assert sols[0][1] == sols[1][1]
+    assert np.max(np.abs(sols[0][0] - sols[1][0])) <= 1e-9 * np.max(np.abs(sols[0][0]))
+    assert np.max(np.abs(sols[0][0] - b)) <= 1e-5 * np.max(np.abs(b))
+
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_option("same_points_global", 1)
+        ctx.set_points(np.ascontiguousarray(y[: n // 2]), y, _lib.KMVP_F64, j_offset=0, M_total=n)
+        with pytest.raises(_lib.KmvpError):
+            ctx.cg_solve("absolute-exponential", a, 1e-9, 10)
+    finally:
+        ctx.close()
+
+
 # ---- the harness end to end: dataset file -> registry -> runner protocol -> result files
 
 def test_runner_end_to_end_on_gpu(tmp_path):
