@@ -253,4 +253,220 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Software-pipelined variant (two target tiles per wave, KS <= MFMA_PIPE_MAX_KS,
+// NT <= MFMA_PIPE_MAX_NT).  rocprofv3 on mfma_kernel at config 3: VALU active 62 % of the
+// cycles, matrix pipe busy 44 %, both at once 12 % -- the two waves of a SIMD run their
+// MFMA and VALU phases one after the other.  Here every wave overlaps them by itself: the
+// distance MFMAs of source tile t+1 are issued between the transcendentals of tile t (the
+// matrix pipe is asynchronous to the wave once an MFMA has issued), and the P.V MFMAs of a
+// target tile run under the VALU work of the next one.  Costs: the squared distances of
+// the next tile live in registers (+16 TW VGPRs) and LDS holds three tile images
+// (t: signal fragments, t+1: source fragments, t+2: in flight).
+constexpr int MFMA_PIPE_MAX_KS = 6;
+constexpr int MFMA_PIPE_MAX_NT = 2;
+// quarter-rate instructions per kernel value: exp2 (Gaussian), sqrt + exp2, rsq
+template <int KERNEL>
+__host__ __device__ constexpr int MFMA_TRANS_PER_PAIR() { return KERNEL == K_ABSEXP ? 2 : 1; }
+
+template <int KERNEL, int KS, int NT>
+__global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs a) {
+  constexpr int TW = 2;
+  constexpr int KD = 16 * KS;
+  constexpr int YS = mfma_y_stride(KS);
+  constexpr int IMG = mfma_image_bytes(KS, NT);
+  constexpr int PIECES = IMG / (16 * BLOCK_THREADS);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3][IMG];
+
+  int tb, seg;
+  block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int64_t i0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * (MFMA_TILE * TW);
+
+  bf16x8 xb[TW][KS];
+#pragma unroll
+  for (int w = 0; w < TW; ++w)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      xb[w][ks] = *reinterpret_cast<const bf16x8*>(a.xa + (i0 + w * MFMA_TILE + r) * KD + ks * 16 + 8 * h);
+
+  int64_t jz[TW], jz_lo = 0, jz_hi = -1;
+#pragma unroll
+  for (int w = 0; w < TW; ++w) jz[w] = -1;
+  if constexpr (KERNEL == K_INVDIST) {
+#pragma unroll
+    for (int w = 0; w < TW; ++w) {
+      const int64_t g = (i0 + w * MFMA_TILE + r) % (a.m_total + 1);
+      jz[w] = (g < a.m_total) ? g - a.j_offset : (int64_t)-1;
+    }
+    const int64_t g_lo = i0 % (a.m_total + 1);
+    const int64_t g_hi = g_lo + (MFMA_TILE * TW - 1);
+    if (g_hi <= a.m_total) {
+      jz_lo = g_lo - a.j_offset;
+      jz_hi = g_hi - a.j_offset;
+    } else {
+      jz_lo = INT64_MIN / 2;
+      jz_hi = INT64_MAX / 2;
+    }
+  }
+
+  f32x16 o[TW][NT];
+  float den[TW];
+#pragma unroll
+  for (int w = 0; w < TW; ++w) {
+    den[w] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) o[w][nt][q] = 0.f;
+  }
+
+  const int64_t t_begin = (int64_t)seg * a.seg_tiles;
+  int64_t t_end = t_begin + a.seg_tiles;
+  if (t_end > a.m_tiles) t_end = a.m_tiles;
+
+  auto stage_tile = [&](int64_t t, int buf) {
+    const unsigned char* src = a.img + t * IMG;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+      const int piece = (p * WAVES_PER_BLOCK + wave) * 1024;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + piece + lane * 16),
+          (__attribute__((address_space(3))) void*)(&lds[buf][piece]), 16, 0, 0);
+    }
+  };
+  // squared distances of one source tile against both target tiles: 2 KS MFMAs
+  auto distances = [&](const unsigned char* ly, f32x16 (&s)[TW]) {
+    bf16x8 ya[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      ya[ks] = *reinterpret_cast<const bf16x8*>(ly + r * YS + (ks * 16 + 8 * h) * 2);
+#pragma unroll
+    for (int w = 0; w < TW; ++w)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s[w][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int w = 0; w < TW; ++w) s[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[ks], xb[w][ks], s[w], 0, 0, 0);
+  };
+
+  if (t_begin >= t_end) {
+    // nothing to do for this segment: the partials still have to be written (zeros)
+  } else {
+    stage_tile(t_begin, 0);
+    if (t_begin + 1 < t_end) stage_tile(t_begin + 1, 1);
+  }
+  __syncthreads();  // vmcnt(0) + barrier: tiles t_begin, t_begin + 1 and the target fragments have landed
+
+  // two register sets for the squared distances, swapped by unrolling the tile loop twice
+  // (a copy per tile would cost 16 TW v_mov on the VALU, which is the busier unit)
+  f32x16 s_a[TW], s_b[TW];
+  if (t_begin < t_end) distances(&lds[0][0], s_a);
+
+  int buf = 0;  // image of tile t
+  auto step = [&](int64_t t, f32x16 (&s_cur)[TW], f32x16 (&s_next)[TW]) {
+    const int buf1 = buf == 2 ? 0 : buf + 1;   // tile t + 1 (landed: waited for at the end of iteration t - 1)
+    const int buf2 = buf1 == 2 ? 0 : buf1 + 1; // tile t + 2 (free: last read in iteration t - 1)
+    if (t + 2 < t_end) stage_tile(t + 2, buf2);
+    const unsigned char* lv = &lds[buf][MFMA_TILE * YS];
+
+    bf16x8 vb[2][NT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned char* row = lv + (nt * 32 + r) * MFMA_V_STRIDE;
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 4 * h) * 2);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 8 + 4 * h) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vb[s2][nt][j] = v0[j];
+          vb[s2][nt][4 + j] = v1[j];
+        }
+      }
+    const int64_t j0 = t * MFMA_TILE;
+    bool check = false;
+    if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
+
+    // Three scheduling regions per source tile, each pairing MFMAs with independent VALU work of
+    // the same wave (an MFMA that cannot enter the matrix pipe yet blocks the wave's following
+    // instructions, so the MFMAs are spread between the transcendentals, not bunched):
+    //   A: distances of tile t + 1 (2 KS MFMAs)      | kernel values of target tile 0
+    //   B: P.V of target tile 0 (2 NT MFMAs)         | kernel values of target tile 1
+    //   C: P.V of target tile 1 (2 NT MFMAs), barrier
+    // (Past the last tile the t + 1 buffer holds stale data; that result is never used.)
+    distances(&lds[buf1][0], s_next);
+
+    bf16x8 pa[TW][2];
+#pragma unroll
+    for (int w = 0; w < TW; ++w) {
+      float p[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float k = mfma_kval<KERNEL>(s_cur[w][q]);
+        if constexpr (KERNEL == K_INVDIST) {
+          if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
+        }
+        p[q] = k;
+        den[w] += k;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pa[w][s2][j] = (__bf16)p[8 * s2 + j];
+      if (w > 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            o[w - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[w - 1][s2], vb[s2][nt], o[w - 1][nt], 0, 0, 0);
+      }
+      // one MFMA, then enough transcendentals to cover its 32 cycles on the matrix pipe
+      if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, MFMA_TRANS_PER_PAIR<KERNEL>() * 16 / (2 * KS) > 0 ? MFMA_TRANS_PER_PAIR<KERNEL>() * 16 / (2 * KS) : 1, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, MFMA_TRANS_PER_PAIR<KERNEL>() * 16 / (2 * NT), 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        o[TW - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TW - 1][s2], vb[s2][nt], o[TW - 1][nt], 0, 0, 0);
+    buf = buf1;
+    __syncthreads();  // tile t + 2 has landed (vmcnt(0)), nobody reads image t any more
+  };
+  int64_t t = t_begin;
+  for (; t + 1 < t_end; t += 2) {
+    step(t, s_a, s_b);
+    step(t + 1, s_b, s_a);
+  }
+  if (t < t_end) step(t, s_a, s_b);
+
+#pragma unroll
+  for (int w = 0; w < TW; ++w) {
+    const float dsum = den[w] + __shfl_xor(den[w], 32);
+    float* part = a.part + ((int64_t)seg * a.n_pad + i0 + w * MFMA_TILE) * (NT * 32);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) part[(int64_t)acc_row(q, h) * (NT * 32) + nt * 32 + r] = o[w][nt][q];
+    if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = dsum;
+  }
+}
+
 }  // namespace kmvp

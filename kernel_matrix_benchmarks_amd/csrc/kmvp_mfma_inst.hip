@@ -12,7 +12,13 @@ namespace kmvp {
 
 template <int KS, int NT>
 static hipError_t launch_one(int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream) {
-  if (TW == 2)
+  if constexpr (KS <= MFMA_PIPE_MAX_KS && NT <= MFMA_PIPE_MAX_NT) {
+    if (TW == 3) {  // two target tiles per wave, software-pipelined
+      hipLaunchKernelGGL((mfma_pipe_kernel<KMVP_KERNEL, KS, NT>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+      return hipGetLastError();
+    }
+  }
+  if (TW >= 2)
     hipLaunchKernelGGL((mfma_kernel<KMVP_KERNEL, KS, NT, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args);
   else
     hipLaunchKernelGGL((mfma_kernel<KMVP_KERNEL, KS, NT, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args);
@@ -32,7 +38,8 @@ static hipError_t launch_nt(int NT, int TW, const MfmaArgs& args, dim3 grid, hip
 
 hipError_t KMVP_FN(int KS, int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream,
                    const char** kernel_name) {
-  if (kernel_name) *kernel_name = "mfma_kernel";
+  if (kernel_name)
+    *kernel_name = (TW == 3 && KS <= MFMA_PIPE_MAX_KS && NT <= MFMA_PIPE_MAX_NT) ? "mfma_pipe_kernel" : "mfma_kernel";
   switch (KS) {
     case 1: return launch_nt<1>(NT, TW, args, grid, stream);
     case 2: return launch_nt<2>(NT, TW, args, grid, stream);

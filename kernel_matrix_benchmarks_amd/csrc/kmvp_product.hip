@@ -474,7 +474,10 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   const int64_t IMG = mfma_image_bytes(KS, NT);
   const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
-  const int TW = c->opt_T == 1 ? 1 : 2;  // target tiles of 32 per wave ("targets_per_lane" option: 1 or 2)
+  // target tiles of 32 per wave ("targets_per_lane" option): 1, 2, or (default, where instantiated)
+  // 2 with the software-pipelined kernel
+  const int TW = c->opt_T == 1 ? 1 : 2;
+  const bool pipelined = TW == 2 && c->opt_T != 2 && KS <= MFMA_PIPE_MAX_KS && NT <= MFMA_PIPE_MAX_NT;
   const int64_t tile = (int64_t)MFMA_TILE * TW * WAVES_PER_BLOCK;
   const int64_t n_pad = round_up(N, tile);
   const int64_t tile_blocks = n_pad / tile;
@@ -530,9 +533,9 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   hipError_t le;
   switch (kernel) {
-    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
-    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
-    default: le = launch_mfma_invdist(KS, NT, TW, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_mfma_invdist(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
   }
   HIP_TRY(c, le);
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));

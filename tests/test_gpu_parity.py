@@ -157,8 +157,14 @@ def test_bfloat16_mfma_matches_reference(case, expected):
     y, x, b = golden_cases.make_inputs(case)
     truth = expected[f"{case['name']}/f64"]
     got, extra = run_plugin(case, y, x, b, "bfloat16")
-    assert got.shape == truth.shape and extra["device_kernel"] == "mfma_kernel"
+    assert got.shape == truth.shape and extra["device_kernel"] in ("mfma_kernel", "mfma_pipe_kernel")
     assert rel_err(got, truth) <= TOL_BF16, rel_err(got, truth)
+    # the non-pipelined instantiations (one / two target tiles per wave) compute the same sums
+    for tiles in (1, 2):
+        other, extra = run_plugin(case, y, x, b, "bfloat16", targets_per_lane=tiles)
+        assert extra["device_kernel"] == "mfma_kernel"
+        assert rel_err(other, truth) <= TOL_BF16
+        assert rel_err(other, got) <= 1e-5, (tiles, rel_err(other, got))
 
 
 def test_config3_attention_65536_row_subset():
