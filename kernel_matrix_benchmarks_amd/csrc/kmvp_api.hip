@@ -89,7 +89,7 @@ void kmvp_destroy(kmvp_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled, &c->y_scaled,
-                    &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch})
+                    &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg})
     release(*b);
   for (int i = 0; i < 3; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -253,7 +253,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
   if (!c) return 0;
   size_t t = 0;
   for (const DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled,
-                          &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch})
+                          &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg})
     t += b->cap;
   return (int64_t)t;
 }

@@ -107,6 +107,7 @@ struct kmvp_ctx {
   DevBuf sortbuf, perm;         // centred path: radix-sort scratch, Morton order of the sources
   DevBuf x_scaled, y_scaled;    // scaled copies (generic path)
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
+  DevBuf xchg;                  // sharded runs: sums in the canonical unpadded layout [column][N] for the all-reduce
   DevBuf scratch;               // CG vectors / dot products
   uint64_t points_ver = 0, signal_ver = 0;
   // what xs / rec / scaled copies currently hold

@@ -106,6 +106,14 @@ __global__ void finish_kernel(const double* __restrict__ sums, double* __restric
   }
 }
 
+// canon[e][i] = sums[e][i] for i < n: drops the path-specific padding before the all-reduce
+__global__ void unpad_kernel(const double* __restrict__ sums, double* __restrict__ canon, int64_t n,
+                             int64_t n_pad, int64_t NE) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= NE * n) return;
+  canon[q] = sums[(q / n) * n_pad + q % n];
+}
+
 __global__ void fill_kernel(double* p, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -118,15 +126,26 @@ __global__ void fill_kernel(double* p, int64_t n, double v) {
 // synchronisation that makes the entry point synchronous (runner.py:138-140 times it).
 int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, int sig) {
   int rc;
-  if (c->comm && c->world > 1) {
-    ncclResult_t r = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, ncclFloat64, ncclSum,
-                                      c->comm, c->stream);
+  const double* sums = (const double*)c->sums.p;
+  if (c->comm) {  // also with world == 1: the one-GPU tests then run the real exchange path
+    // The padded length n_pad belongs to the kernel a rank happened to choose (tile sizes differ
+    // between the paths, and the auto policy looks at the rank's own clouds), so the exchange uses
+    // the canonical unpadded layout [column][N]: every rank contributes exactly NE * N doubles.
+    const int64_t NE = count / n_pad;
+    if ((rc = ensure(c, c->xchg, (size_t)NE * std::max<int64_t>(N, 1) * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(unpad_kernel, dim3(blocks_for(NE * N)), dim3(256), 0, c->stream, sums, (double*)c->xchg.p,
+                       N, n_pad, NE);
+    HIP_TRY(c, hipGetLastError());
+    ncclResult_t r = g_rccl.AllReduce(c->xchg.p, c->xchg.p, (size_t)(NE * N), ncclFloat64, ncclSum, c->comm,
+                                      c->stream);
     if (r != ncclSuccess)
       return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    sums = (const double*)c->xchg.p;
+    n_pad = N;
   }
   if ((rc = ensure(c, c->out, (size_t)std::max<int64_t>(N, 1) * E * sizeof(double)))) return rc;
   hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1))), dim3(256), 0, c->stream,
-                     (const double*)c->sums.p, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0);
+                     sums, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -575,6 +594,22 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
   if (!c->have_signal) return fail(c, KMVP_E_INVALID, "kmvp_set_signal has not been called");
   HIP_TRY(c, hipSetDevice(c->device));
+  if (c->M == 0 && c->N > 0 && c->comm && c->world > 1) {
+    // a rank whose source slice is empty still owes the other ranks its (zero) share of the sums
+    const int sig0 = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
+    const int E = c->density ? 1 : c->E;
+    const int64_t NE = sig0 == SIG_NORM ? E + 1 : E;
+    int rc = ensure(c, c->sums, (size_t)NE * c->N * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->sums.p, 0, (size_t)NE * c->N * sizeof(double), c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    c->last_kernel_name = "none";
+    if (c->density && normalise) {  // every rank takes the all-ones shortcut below: no exchange
+    } else {
+      return finish_product(c, NE * c->N, c->N, c->N, E, sig0);
+    }
+  }
   if (c->N == 0 || c->M == 0) {
     // empty clouds: a = 0 (N,E); nothing to launch
     const int E = c->density ? 1 : c->E;

@@ -241,19 +241,44 @@ def test_source_shard_with_global_offset_matches_oracle():
 
 
 def test_single_rank_rccl_communicator():
-    """kmvp_comm_get_unique_id / kmvp_comm_init / ncclAllReduce with world == 1 on the one GPU."""
-    y, b = kmvp_oracle.uniform_cube(1000, 3)
+    """kmvp_comm_get_unique_id / kmvp_comm_init / ncclAllReduce with world == 1 on the one GPU.
+    With a communicator attached every path goes through the exchange in the canonical unpadded
+    layout [column][N] (ranks may pick kernels with different tile padding): lowd / fast / cfast /
+    mfma kernels, N not a multiple of any tile size."""
+    n = 1000 + 37
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    cases = [("gaussian", True, _lib.KMVP_F32, 0, "lowd_kernel"), ("gaussian", True, _lib.KMVP_F32, 1, "fast_kernel"),
+             ("inverse-distance", False, _lib.KMVP_F32, 2, "cfast_kernel"),
+             ("absolute-exponential", True, _lib.KMVP_F64, 0, "lowd_kernel")]
+    for kernel, norm, dtype, fast, kname in cases:
+        npdt = np.float64 if dtype == _lib.KMVP_F64 else np.float32
+        ctx = _lib.Context(0)
+        try:
+            ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+            ctx.set_option("fast_sqdists", fast)
+            ctx.set_points(y.astype(npdt), None, dtype)
+            ctx.set_signal(b.astype(npdt))
+            ctx.run(kernel, norm)
+            got = ctx.get_result(n, 1)
+            assert ctx.last_kernel_name == kname
+        finally:
+            ctx.close()
+        want = kmvp_oracle.product(kernel=kernel, source_points=y, source_signal=b, normalize_rows=norm)
+        assert rel_err(got, want) <= (TOL64 if dtype == _lib.KMVP_F64 else TOL32), (kernel, kname)
+    # bf16 matrix-core path, E > 1
+    yd = np.random.RandomState(5).rand(300, 32) / np.sqrt(32)
+    bd = np.random.RandomState(6).randn(300, 5)
     ctx = _lib.Context(0)
     try:
         ctx.comm_init(_lib.comm_unique_id(), 0, 1)
-        ctx.set_points(y.astype(np.float32), None, _lib.KMVP_F32)
-        ctx.set_signal(b.astype(np.float32))
-        ctx.run("gaussian", True)
-        got = ctx.get_result(1000, 1)
+        ctx.set_points(yd.astype(np.float32), None, _lib.KMVP_BF16)
+        ctx.set_signal(bd.astype(np.float32))
+        ctx.run("absolute-exponential", True)
+        got = ctx.get_result(300, 5)
     finally:
         ctx.close()
-    want = kmvp_oracle.product(kernel="gaussian", source_points=y, source_signal=b, normalize_rows=True)
-    assert rel_err(got, want) <= TOL32
+    want = kmvp_oracle.product(kernel="absolute-exponential", source_points=yd, source_signal=bd, normalize_rows=True)
+    assert rel_err(got, want) <= TOL_BF16
 
 
 def test_abi_error_behaviour():
