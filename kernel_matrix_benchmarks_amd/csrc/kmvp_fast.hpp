@@ -52,8 +52,10 @@ __host__ __device__ constexpr int fast_stage_bytes(int KS, int EB) {
   return (FAST_STAGE * fast_tile_bytes(KS, EB) + 4095) / 4096 * 4096;
 }
 
+__host__ __device__ constexpr int fast_target_row(int D) { return D <= 3 ? 4 : 8; }  // floats per target
+
 struct FastArgs {
-  const __bf16* xa;          // target operands [n_tiles][KS][32][16]
+  const float* xr;           // targets [n_pad][fast_target_row(D)]: centred scaled coordinates, then |x'|^2
   const unsigned char* img;  // source stages [m_stages][stage_bytes]
   double* part;              // partial sums [segments][NE][n_pad]
   int64_t n_pad;
@@ -78,8 +80,61 @@ __device__ __forceinline__ float fast_kval(float s) {
   }
 }
 
-template <int KERNEL, int KS, int SIG, int TT>
+// bf16 pieces of an fp32 value as fp32 numbers: v == hi + mid + lo exactly
+__device__ __forceinline__ void fast_split3f(float v, float& hi, float& mid, float& lo) {
+  hi = (float)(__bf16)v;
+  const float r1 = v - hi;
+  mid = (float)(__bf16)r1;
+  lo = (float)(__bf16)(r1 - mid);
+}
+
+// element k of a target's augmented row: per d (x_h, x_m, x_h, x_l, x_m, x_h), then 1, 1, 1,
+// |x'|^2 h, m, l, then zeros.  hi/mid/lo[D] hold the split of |x'|^2.
+template <int D, int K>
+__device__ __forceinline__ float fast_target_elem(const float (&hi)[D + 1], const float (&mid)[D + 1],
+                                                  const float (&lo)[D + 1]) {
+  if constexpr (K < 6 * D) {
+    constexpr int d = K / 6, role = K % 6;
+    if constexpr (role == 0 || role == 2 || role == 5) return hi[d];
+    if constexpr (role == 1 || role == 4) return mid[d];
+    return lo[d];
+  } else if constexpr (K < 6 * D + 3) {
+    return 1.f;
+  } else if constexpr (K == 6 * D + 3) {
+    return hi[D];
+  } else if constexpr (K == 6 * D + 4) {
+    return mid[D];
+  } else if constexpr (K == 6 * D + 5) {
+    return lo[D];
+  } else {
+    return 0.f;
+  }
+}
+
+template <int D, int KS, int J>
+__device__ __forceinline__ void fast_target_fill(bf16x8& out, int h, const float (&hi)[D + 1],
+                                                 const float (&mid)[D + 1], const float (&lo)[D + 1]) {
+  if constexpr (J < 8) {
+    const float v0 = fast_target_elem<D, KS * 16 + J>(hi, mid, lo);      // lane half 0: k = 16 ks + j
+    const float v1 = fast_target_elem<D, KS * 16 + 8 + J>(hi, mid, lo);  // lane half 1: k = 16 ks + 8 + j
+    out[J] = (__bf16)(h ? v1 : v0);
+    fast_target_fill<D, KS, J + 1>(out, h, hi, mid, lo);
+  }
+}
+
+template <int D, int KS>
+__device__ __forceinline__ void fast_target_operand(bf16x8 (&xb)[fast_ksteps(D)], int h, const float (&hi)[D + 1],
+                                                    const float (&mid)[D + 1], const float (&lo)[D + 1]) {
+  if constexpr (KS < fast_ksteps(D)) {
+    fast_target_fill<D, KS, 0>(xb[KS], h, hi, mid, lo);
+    fast_target_operand<D, KS + 1>(xb, h, hi, mid, lo);
+  }
+}
+
+template <int KERNEL, int D, int SIG, int TT>
 __global__ void __launch_bounds__(BLOCK_THREADS) fast_kernel(const FastArgs a) {
+  constexpr int KS = fast_ksteps(D);
+  constexpr int RD = fast_target_row(D);
   constexpr int EB = (SIG == SIG_DENSITY) ? 0 : 1;
   constexpr int NE = (SIG == SIG_NORM) ? 2 : 1;
   constexpr int RB = fast_row_bytes(KS);
@@ -96,13 +151,25 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fast_kernel(const FastArgs a) {
   const int h = lane >> 5;
   const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;  // first target tile of the wave
 
+  // The B operand of this lane's targets is built in registers from 4 (D <= 3) or 8 floats per
+  // target; a pre-packed operand array would be 16 KS bf16 per target, re-read once per source
+  // segment (at the headline shape 3 GB of L2 fills per launch instead of 0.8 GB).
   bf16x8 xb[TT][KS];
   int64_t jz[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    const float* row = a.xr + ((tile0 + tt) * FAST_TILE + r) * RD;
+    float v[RD];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      xb[tt][ks] = *reinterpret_cast<const bf16x8*>(a.xa + (((tile0 + tt) * KS + ks) * 32 + r) * 16 + 8 * h);
+    for (int q = 0; q < RD / 4; ++q) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(row + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * q + j] = w[j];
+    }
+    float hi[D + 1], mid[D + 1], lo[D + 1];
+#pragma unroll
+    for (int d = 0; d <= D; ++d) fast_split3f(v[d], hi[d], mid[d], lo[d]);
+    fast_target_operand<D, 0>(xb[tt], h, hi, mid, lo);
     if constexpr (KERNEL == K_INVDIST) {
       const int64_t g = ((tile0 + tt) * FAST_TILE + r) % (a.m_total + 1);
       jz[tt] = (g < a.m_total) ? g - a.j_offset : (int64_t)-1;

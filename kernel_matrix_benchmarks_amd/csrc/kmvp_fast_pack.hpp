@@ -57,42 +57,23 @@ __device__ __forceinline__ void fast_split3(float v, __bf16& hi, __bf16& mid, __
   lo = (__bf16)(r1 - (float)mid);
 }
 
-// target operands [tile][KS][32][16]: per d (x_h, x_m, x_h, x_l, x_m, x_h), then 1,1,1, |x'|^2 h,m,l
+// targets [n_pad][RD]: centred scaled coordinates x'_0 .. x'_{D-1}, then |x'|^2 (accumulated in
+// double, rounded once), zeros up to RD = fast_target_row(D); pad targets are all zero.  The
+// kernel splits these into the bf16 operand itself.
 __global__ void pack_fast_targets_kernel(const float* __restrict__ x, const float* __restrict__ centre,
-                                         __bf16* __restrict__ xa, int64_t n, int64_t n_pad, int D,
-                                         int KS, float scale) {
+                                         float* __restrict__ xr, int64_t n, int64_t n_pad, int D, int RD,
+                                         float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
-  const int64_t tile = i / FAST_TILE;
-  const int r = (int)(i % FAST_TILE);
-  auto put = [&](int k, __bf16 v) { xa[((tile * KS + k / 16) * 32 + r) * 16 + (k % 16)] = v; };
-  const __bf16 zero = (__bf16)0.f, one = (__bf16)1.f;
-  if (i >= n) {
-    for (int k = 0; k < 16 * KS; ++k) put(k, zero);
-    return;
-  }
+  float* row = xr + i * RD;
   double sq = 0.0;
   for (int d = 0; d < D; ++d) {
-    const float v = (x[i * D + d] - centre[d]) * scale;
+    const float v = i < n ? (x[i * D + d] - centre[d]) * scale : 0.f;
     sq += (double)v * (double)v;
-    __bf16 vh, vm, vl;
-    fast_split3(v, vh, vm, vl);
-    put(6 * d + 0, vh);
-    put(6 * d + 1, vm);
-    put(6 * d + 2, vh);
-    put(6 * d + 3, vl);
-    put(6 * d + 4, vm);
-    put(6 * d + 5, vh);
+    row[d] = v;
   }
-  __bf16 sh, sm, sl;
-  fast_split3((float)sq, sh, sm, sl);
-  put(6 * D + 0, one);
-  put(6 * D + 1, one);
-  put(6 * D + 2, one);
-  put(6 * D + 3, sh);
-  put(6 * D + 4, sm);
-  put(6 * D + 5, sl);
-  for (int k = 6 * D + 6; k < 16 * KS; ++k) put(k, zero);
+  row[D] = (float)sq;
+  for (int d = D + 1; d < RD; ++d) row[d] = 0.f;
 }
 
 // source stages: per tile [32 rows x row_bytes] (per d (-2y_h, -2y_h, -2y_m, -2y_h, -2y_m, -2y_l),

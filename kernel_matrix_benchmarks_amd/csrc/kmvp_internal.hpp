@@ -59,11 +59,11 @@ constexpr int FAST_DEFAULT_TT = 4;
 // auto mode: scaled squared radius of the clouds below which the expansion is used
 constexpr float FAST_AUTO_RADIUS2 = 8.0f;
 struct FastArgs;
-hipError_t launch_fast_gaussian(int KS, int sig, int TT, const FastArgs& args, dim3 grid,
+hipError_t launch_fast_gaussian(int D, int sig, int TT, const FastArgs& args, dim3 grid,
                                 hipStream_t stream, const char** kernel_name);
-hipError_t launch_fast_absexp(int KS, int sig, int TT, const FastArgs& args, dim3 grid,
+hipError_t launch_fast_absexp(int D, int sig, int TT, const FastArgs& args, dim3 grid,
                               hipStream_t stream, const char** kernel_name);
-hipError_t launch_fast_invdist(int KS, int sig, int TT, const FastArgs& args, dim3 grid,
+hipError_t launch_fast_invdist(int D, int sig, int TT, const FastArgs& args, dim3 grid,
                                hipStream_t stream, const char** kernel_name);
 
 

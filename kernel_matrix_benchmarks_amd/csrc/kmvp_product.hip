@@ -328,9 +328,10 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
   float* centre = (float*)c->aux.p;  // written by kmvp_set_points
   if (pts_stale) {
-    if ((rc = ensure(c, c->xs, (size_t)n_pad * KS * 16 * 2))) return rc;
+    const int RD = fast_target_row(D);
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * RD * sizeof(float)))) return rc;
     hipLaunchKernelGGL(pack_fast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
-                       centre, (__bf16*)c->xs.p, N, n_pad, D, KS, scale);
+                       centre, (float*)c->xs.p, N, n_pad, D, RD, scale);
   }
   if (sig_stale) {
     if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
@@ -348,7 +349,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
 
   if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
   FastArgs a;
-  a.xa = (const __bf16*)c->xs.p;
+  a.xr = (const float*)c->xs.p;
   a.img = (const unsigned char*)c->rec.p;
   a.part = (double*)c->part.p;
   a.n_pad = n_pad;
@@ -364,9 +365,9 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   hipError_t le;
   switch (kernel) {
-    case K_GAUSSIAN: le = launch_fast_gaussian(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
-    case K_ABSEXP: le = launch_fast_absexp(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
-    default: le = launch_fast_invdist(KS, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_GAUSSIAN: le = launch_fast_gaussian(D, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_fast_absexp(D, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_fast_invdist(D, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
   }
   if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
   HIP_TRY(c, le);
