@@ -38,11 +38,12 @@ KERNELS = {"gaussian": "gaussian", "absexp": "absolute-exponential", "invdist": 
 # per pair: flops counting fma = 2, transcendental = 1 (3D + 2E + 1 for gaussian, D=3, E=1)
 # and VALU issue slots counting a quarter-rate transcendental as 4
 FLOPS_PER_PAIR = {"gaussian": 12, "inverse-distance": 12, "absolute-exponential": 13}
-# VALU issue slots per pair of the two pair-loop kernels: lowd_kernel (difference form: 6 for the
-# squared distance + transcendental(s) + 1 FMA) and fast_kernel (squared distance on the matrix
-# cores: only the transcendental(s) + 1 FMA stay on the VALU)
+# VALU issue slots per pair of the pair-loop kernels: lowd_kernel (difference form: 6 for the
+# squared distance of the caller's coordinates + 1 multiply by log2 e where the kernel is an
+# exponential + transcendental(s) + 1 FMA) and fast_kernel (squared distance on the matrix cores:
+# only the transcendental(s) + 1 FMA stay on the VALU)
 SLOTS_PER_PAIR = {
-    "lowd_kernel": {"gaussian": 11, "inverse-distance": 11, "absolute-exponential": 15},
+    "lowd_kernel": {"gaussian": 12, "inverse-distance": 11, "absolute-exponential": 16},
     "fast_kernel": {"gaussian": 5, "inverse-distance": 5, "absolute-exponential": 9},
     # centred form: + ~0.7 operand rebuild + ~0.6 closest-pair test per pair
     "cfast_kernel": {"gaussian": 6.3, "inverse-distance": 6.3, "absolute-exponential": 10.3},

@@ -7,10 +7,11 @@
 // accuracy of small s.  Here
 //   * the sources are sorted along a Morton curve once per set_points (hipcub radix sort),
 //     so that 128 consecutive sources form a spatially compact group with centre c_g;
-//   * a group's rows are stored relative to c_g (y' = y - c_g, |y'| <= R_g, split three ways
-//     into bf16 as in kmvp_fast.hpp);
+//   * a group's rows are stored relative to c_g (y' = (y - c_g) * kernel constant, |y'| <= R_g,
+//     split three ways into bf16 as in kmvp_fast.hpp); coordinates themselves are never
+//     centred or scaled, so clusters far from each other or from the origin lose nothing;
 //   * the TARGET operand is rebuilt on the fly for every (target tile, group):
-//     x'' = x - c_g, split three ways, |x''|^2 split three ways.
+//     x'' = (x - c_g) * kernel constant, split three ways, |x''|^2 split three ways.
 // Then |x''|^2 ~ s and the error of s is eps32 * (s + 2 R_g sqrt(s) + 2 R_g^2): RELATIVE
 // accuracy ~ eps32 for every pair farther apart than the group radius.  Pairs closer than
 // that (s < tau_g = kappa R_g^2; a fraction ~1e-6 of all pairs, plus the diagonal) are
@@ -49,7 +50,7 @@ constexpr int CF_STAGE_BYTES = (CF_STAGE_GROUPS * CF_GROUP_BYTES + 4095) / 4096 
 constexpr float CF_KAPPA = 0.03f;  // tau_g = kappa * R_g^2: below it a pair is recomputed exactly
 
 struct CfastArgs {
-  const float* xraw;         // targets [n_pad][4]: (x0..x3) globally centred and scaled; unused dims 0
+  const float* xraw;         // targets [n_pad][4]: the caller's fp32 coordinates, untouched; unused dims 0
   const unsigned char* img;  // source stages [m_stages][CF_STAGE_BYTES]
   double* part;              // partial sums [segments][NE][n_pad]
   int64_t n_pad;
@@ -60,6 +61,7 @@ struct CfastArgs {
   int chunk_stages;
   int64_t j_offset;
   int64_t m_total;
+  float scale;               // the kernel's constant, applied AFTER a difference is formed
 };
 
 template <int KERNEL>
@@ -159,8 +161,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfast_kernel(const CfastArgs a)
       bf16x8 xb[TT][2];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-        const float x0 = x[tt][0] - cen[0], x1 = x[tt][1] - cen[1];
-        const float x2 = x[tt][2] - cen[2], x3 = x[tt][3] - cen[3];
+        // differences of the caller's coordinates first, the kernel's constant afterwards: a
+        // difference of nearby fp32 numbers is (nearly) exact, whatever their distance from the
+        // origin; scaling or centring the cloud beforehand would round every coordinate
+        const float x0 = (x[tt][0] - cen[0]) * a.scale, x1 = (x[tt][1] - cen[1]) * a.scale;
+        const float x2 = (x[tt][2] - cen[2]) * a.scale, x3 = (x[tt][3] - cen[3]) * a.scale;
         const float sq = fmaf(x3, x3, fmaf(x2, x2, fmaf(x1, x1, x0 * x0)));
         const float xa = h ? x1 : x0, xc = h ? x3 : x2;
         float ah, am, al, ch, cm, cl, sh, sm, sl;
@@ -210,14 +215,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfast_kernel(const CfastArgs a)
 #pragma unroll
           for (int q = 3; q < 15; q += 2) dmin = fminf(fminf(dmin, d[q]), d[q + 1]);
           dmin = fminf(dmin, d[15]);
-          if (__any(dmin <= tau)) {
+          // (negated comparisons: a NaN -- non-finite coordinates poison a whole group's centre --
+          // also takes the exact branch, where inf - x gives s = inf, k = 0 as in the reference)
+          if (__any(!(dmin > tau))) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-              if (d[q] <= tau) {
+              if (!(d[q] > tau)) {
                 const int row = rt * 32 + acc_row(q, h);
                 const cf32x4 yr = lraw[row];
-                const float e0 = x[tt][0] - yr[0], e1 = x[tt][1] - yr[1];
-                const float e2 = x[tt][2] - yr[2], e3 = x[tt][3] - yr[3];
+                const float e0 = (x[tt][0] - yr[0]) * a.scale, e1 = (x[tt][1] - yr[1]) * a.scale;
+                const float e2 = (x[tt][2] - yr[2]) * a.scale, e3 = (x[tt][3] - yr[3]) * a.scale;
                 float sx = fmaf(e3, e3, fmaf(e2, e2, fmaf(e1, e1, e0 * e0)));
                 if constexpr (KERNEL == K_INVDIST) {
                   if (lidx[row] == jz[tt]) sx = INFINITY;

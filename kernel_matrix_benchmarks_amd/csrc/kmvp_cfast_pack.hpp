@@ -33,12 +33,11 @@ __global__ void cfast_morton_kernel(const float* __restrict__ y, const float* __
 }
 
 // One workgroup of CF_GROUP threads per group of sorted sources: centre = bounding-box midpoint of the
-// group (in globally centred, scaled coordinates), tau = kappa * max |y - c|^2, rows, signal,
-// fp32 coordinates, original global index.
+// group in the caller's coordinates, rows y' = (y - c) * scale, tau = kappa * max |y'|^2, signal,
+// the caller's fp32 coordinates, original global index.
 __global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
     const float* __restrict__ y, const float* __restrict__ b, const int* __restrict__ perm,
-    const float* __restrict__ centre, unsigned char* __restrict__ img, int64_t m, int D, int EB,
-    float scale, int64_t j_offset) {
+    unsigned char* __restrict__ img, int64_t m, int D, int EB, float scale, int64_t j_offset) {
   const int64_t group = blockIdx.x;
   const int rr = threadIdx.x;
   const int64_t k = group * CF_GROUP + rr;  // position in the sorted order
@@ -47,7 +46,7 @@ __global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
   const int src = perm[k];  // pad positions carry indices >= m
   const bool live = src < m;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int d = 0; d < D; ++d) v[d] = live ? (y[(int64_t)src * D + d] - centre[d]) * scale : 0.f;
+  for (int d = 0; d < D; ++d) v[d] = live ? y[(int64_t)src * D + d] : 0.f;
   // group centre: midpoint of the live points' bounding box (wave reductions, then across the
   // waves of the workgroup through LDS)
   __shared__ float red_lo[4][CF_GROUP / 64], red_hi[4][CF_GROUP / 64], red_r2[CF_GROUP / 64];
@@ -75,7 +74,7 @@ __global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
   float yr[4];
   double sq = 0.0;
   for (int d = 0; d < 4; ++d) {
-    yr[d] = live ? v[d] - c[d] : 0.f;
+    yr[d] = live ? (v[d] - c[d]) * scale : 0.f;
     sq += (double)yr[d] * (double)yr[d];
   }
   float r2 = (float)sq;
@@ -125,13 +124,12 @@ __global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
   reinterpret_cast<int*>(g + CF_OFF_IDX)[rr] = live ? (int)(j_offset + src) : -1;
 }
 
-// targets [n_pad][4]: globally centred, scaled coordinates (unused dimensions and pad targets 0)
-__global__ void pack_cfast_targets_kernel(const float* __restrict__ x, const float* __restrict__ centre,
-                                          float* __restrict__ xraw, int64_t n, int64_t n_pad, int D,
-                                          float scale) {
+// targets [n_pad][4]: the caller's coordinates (unused dimensions and pad targets 0)
+__global__ void pack_cfast_targets_kernel(const float* __restrict__ x, float* __restrict__ xraw, int64_t n,
+                                          int64_t n_pad, int D) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
-  for (int d = 0; d < 4; ++d) xraw[i * 4 + d] = (i < n && d < D) ? (x[i * D + d] - centre[d]) * scale : 0.f;
+  for (int d = 0; d < 4; ++d) xraw[i * 4 + d] = (i < n && d < D) ? x[i * D + d] : 0.f;
 }
 
 }  // namespace kmvp

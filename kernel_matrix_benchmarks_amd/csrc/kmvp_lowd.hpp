@@ -44,7 +44,7 @@ enum : int {
 
 template <typename real>
 struct LowdArgs {
-  const real* xs;    // targets, SoA: xs[d * n_pad + i], kernel constant folded in
+  const real* xs;    // targets, SoA: xs[d * n_pad + i], the caller's coordinates
   const real* rec;   // source records, [m_pad][R]
   double* part;      // partial sums [segments][NE][n_pad]
   int64_t n;         // targets
@@ -60,13 +60,16 @@ struct LowdArgs {
 
 __device__ __forceinline__ float kexp2(float v) { return __builtin_amdgcn_exp2f(v); }
 
-// kernel value from the squared distance of the (pre-scaled) coordinates
+// kernel value from the squared distance s of the caller's coordinates (difference form,
+// bruteforce.py:53-54).  The constant that turns exp() into the hardware's exp2() multiplies
+// the squared distance, not the coordinates: scaling x and y before the subtraction would
+// round every coordinate by eps |x| and lose the pairs of clouds far from the origin.
 template <int KERNEL>
 __device__ __forceinline__ float kval(float s) {
   if constexpr (KERNEL == K_GAUSSIAN) {
-    return kexp2(-s);  // coordinates carry sqrt(log2 e): exp(-|x-y|^2) = 2^(-s)
+    return kexp2(s * -1.4426950408889634f);  // exp(-s) = 2^(-s log2 e)
   } else if constexpr (KERNEL == K_ABSEXP) {
-    return kexp2(-__builtin_amdgcn_sqrtf(s));  // coordinates carry log2 e
+    return kexp2(__builtin_amdgcn_sqrtf(s) * -1.4426950408889634f);
   } else {
     return __builtin_amdgcn_rsqf(s);  // 1/sqrt(0) = inf, as the reference's 1/np.sqrt
   }
@@ -116,7 +119,8 @@ __device__ __forceinline__ float kval(float s, const double*) {
   return kval<KERNEL>(s);
 }
 
-// coordinate pre-scale that turns exp() into the hardware's exp2()
+// the constant the matrix-core paths (kmvp_fast.hpp, kmvp_cfast.hpp, kmvp_mfma.hpp) multiply
+// CENTRED coordinates with, so that their MFMA tile is the exponent of exp2() directly
 template <int KERNEL, typename real>
 __host__ __device__ inline real coord_scale() {
   if constexpr (sizeof(real) == 8) return (real)1;

@@ -190,7 +190,7 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   const int NE = sig == SIG_NORM ? E + 1 : E;
   const int64_t N = c->N, M = c->M;
   const bool specialised = D <= LOWD_MAX_D && E <= LOWD_MAX_E;
-  const real scale = scale_for<real>(kernel);
+  const real scale = (real)1;  // difference form: the caller's coordinates, untouched (kval scales s)
   const real* x_raw = (const real*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   int rc;
 
@@ -429,13 +429,13 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   if (pts_stale) {
     if ((rc = ensure(c, c->xs, (size_t)n_pad * 4 * sizeof(float)))) return rc;
     hipLaunchKernelGGL(pack_cfast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
-                       centre, (float*)c->xs.p, N, n_pad, D, scale);
+                       (float*)c->xs.p, N, n_pad, D);
   }
   if (sig_stale) {
     if ((rc = ensure(c, c->rec, (size_t)m_stages * CF_STAGE_BYTES))) return rc;
     hipLaunchKernelGGL(pack_cfast_sources_kernel, dim3((unsigned)(m_alloc / CF_GROUP)), dim3(CF_GROUP), 0,
                        c->stream, (const float*)c->y_raw.p, (const float*)c->b_raw.p, (const int*)c->perm.p,
-                       centre, (unsigned char*)c->rec.p, M, D, EB, scale, c->j_offset);
+                       (unsigned char*)c->rec.p, M, D, EB, scale, c->j_offset);
   }
   HIP_TRY(c, hipGetLastError());
   c->packed_points_ver = c->points_ver;
@@ -448,6 +448,7 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
   CfastArgs a;
   a.xraw = (const float*)c->xs.p;
+  a.scale = scale;
   a.img = (const unsigned char*)c->rec.p;
   a.part = (double*)c->part.p;
   a.n_pad = n_pad;

@@ -148,6 +148,41 @@ def test_fast_sqdists_auto_policy():
     assert rel_err(got, want) <= TOL32
 
 
+def test_clusters_far_apart_and_non_finite_points():
+    """Coordinates are never centred or scaled before a difference is formed: two unit clusters
+    1e4 apart (bounding-box midpoint far from both) keep the accuracy of the difference form of
+    the reference on the same float32 inputs; non-finite points behave as in the reference
+    (a source at infinity contributes exp(-inf) = 1/inf = 0, a NaN target gives a NaN row)."""
+    rs = np.random.RandomState(11)
+    n = 4000
+    y = rs.rand(n, 3)
+    y[n // 2:] += 1e4
+    b = rs.randn(n, 1)
+    y32 = y.astype(np.float32).astype(np.float64)  # what every float32 backend is handed
+    for kernel in golden_cases.KERNELS:
+        want = kmvp_oracle.product(kernel=kernel, source_points=y32, source_signal=b)
+        for opts in (dict(), dict(fast_sqdists=False)):
+            got, extra = run_plugin(dict(kernel=kernel, D=3), y, None, b, "float32", **opts)
+            assert extra["device_kernel"] == ("lowd_kernel" if opts else "cfast_kernel")
+            assert rel_err(got, want) <= TOL32, (kernel, extra["device_kernel"], rel_err(got, want))
+
+    y = rs.rand(1500, 3)
+    y[7] = np.inf
+    x = rs.rand(700, 3)
+    x[5, 1] = np.nan
+    b = rs.randn(1500, 1)
+    for kernel in golden_cases.KERNELS:
+        with np.errstate(all="ignore"):
+            want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b)
+        assert np.isnan(want[5]).all() and np.isfinite(np.delete(want, 5, axis=0)).all()
+        for opts in (dict(), dict(fast_sqdists=False), dict(fast_sqdists="centred")):
+            if kernel == "inverse-distance" and opts.get("fast_sqdists") == "centred":
+                continue  # index-based zero rule on distinct points: difference form only
+            got, extra = run_plugin(dict(kernel=kernel, D=3), y, x, b, "float32", **opts)
+            assert np.isnan(got[5]).all(), (kernel, extra["device_kernel"])
+            assert rel_err(np.delete(got, 5, axis=0), np.delete(want, 5, axis=0)) <= TOL32, (kernel, extra["device_kernel"])
+
+
 TOL_BF16 = 1e-2  # bf16 inputs (8-bit mantissa) with fp32 accumulation; measured 2.4e-3 .. 4e-3
 HIGH_D = [c for c in CASES if c["D"] >= 16]
 
