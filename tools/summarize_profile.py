@@ -26,7 +26,8 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         names[r["Dispatch_Id"]] = r["Kernel_Name"]
     for (disp, counter), v in agg.items():
         per_kernel[names[disp].split("(")[0]][counter].append(v)
-lines = ["# rocprofv3 summary of `python bench.py` (N=M=1e6 Gaussian, D=3, E=1, f32)", "",
+bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+lines = [f"# rocprofv3 summary of `python bench.py`: {bench['config']['workload']}", "",
          "## kernel stats (--kernel-trace --stats)", "", "```"]
 lines += [l.rstrip() for l in open(stats)]
 lines += ["```", "", "## PMC counters, mean per launch (separate --pmc passes)", "",
@@ -38,7 +39,6 @@ for k in sorted(per_kernel):
         mean = sum(vals) / len(vals)
         lines.append(f"| `{k[-60:]}` | {c} | {mean:,.1f} |")
         summary.setdefault(k, {})[c] = mean
-bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
 want = bench.get("roofline", {}).get("kernel", "lowd_kernel")
 main = next((k for k in summary if want in k), None)
 if main and "FETCH_SIZE" in summary[main]:
