@@ -183,6 +183,61 @@ def test_clusters_far_apart_and_non_finite_points():
             assert rel_err(np.delete(got, 5, axis=0), np.delete(want, 5, axis=0)) <= TOL32, (kernel, extra["device_kernel"])
 
 
+def test_matrix_core_kernels_reproducible_and_tile_count_independent():
+    """LDS-DMA staged kernels must not depend on timing: bitwise identical results run to run at a
+    size where every CU is busy, and the same sums (to float32 rounding) whatever the number of
+    target tiles per wave."""
+    n = 300_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    y32, b32 = y.astype(np.float32), b.astype(np.float32)
+
+    def product(kernel, fast, tiles=0, norm=False):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_option("fast_sqdists", fast)
+            if tiles:
+                ctx.set_option("fast_tiles", tiles)
+            ctx.set_points(y32, None, _lib.KMVP_F32)
+            ctx.set_signal(b32)
+            outs = []
+            for _ in range(3):
+                ctx.run(kernel, norm)
+                outs.append(ctx.get_result(n, 1))
+            name = ctx.last_kernel_name
+        finally:
+            ctx.close()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (kernel, name, tiles)
+        return outs[0], name
+
+    for kernel, fast, kname in (("gaussian", 1, "fast_kernel"), ("inverse-distance", 2, "cfast_kernel"),
+                                ("absolute-exponential", 2, "cfast_kernel"), ("gaussian", 2, "cfast_kernel")):
+        base, name = product(kernel, fast, 1)
+        assert name == kname
+        scale = np.max(np.abs(base))
+        for tiles in (2, 4):
+            other, _ = product(kernel, fast, tiles)
+            assert np.max(np.abs(other - base)) <= 5e-6 * scale, (kernel, kname, tiles, np.max(np.abs(other - base)) / scale)
+
+    m, D, E = 16384, 64, 64
+    rs = np.random.RandomState(m + D)
+    yd = (rs.rand(m, D) / np.sqrt(D)).astype(np.float32)
+    bd = rs.randn(m, E).astype(np.float32)
+    for T in (0, 1, 2):  # pipelined / one / two target tiles per wave
+        ctx = _lib.Context(0)
+        try:
+            if T:
+                ctx.set_option("targets_per_lane", T)
+            ctx.set_points(yd, None, _lib.KMVP_BF16)
+            ctx.set_signal(bd)
+            outs = []
+            for _ in range(3):
+                ctx.run("absolute-exponential", True)
+                outs.append(ctx.get_result(m, E))
+        finally:
+            ctx.close()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), T
+
+
 TOL_BF16 = 1e-2  # bf16 inputs (8-bit mantissa) with fp32 accumulation; measured 2.4e-3 .. 4e-3
 HIGH_D = [c for c in CASES if c["D"] >= 16]
 
