@@ -108,6 +108,9 @@ def main():
 
     import numpy as np
 
+    # the host driver of this pool only supports dmabuf IPC (RCCL across processes needs it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     # Load the HIP library (system ROCm runtime) BEFORE torch, so that every GPU call of
     # this process goes through one ROCm stack; torch is only used for the gloo
     # rendezvous / barrier / max-over-ranks and never touches the GPU here.
