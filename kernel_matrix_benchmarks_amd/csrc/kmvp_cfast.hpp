@@ -19,9 +19,15 @@
 // group image -- which is also where the inverse-distance zero rule (bruteforce.py:13-14,
 // on ORIGINAL source indices) and an exact s = 0 on the diagonal are applied.
 //
-// VALU cost per pair: transcendental(s) + 1 FMA + ~0.7 (operand rebuild, amortised over the
-// 128 sources of a group) + 0.6 (rare-branch test) ~ 6.3 issue slots against 11 for the
-// difference form.  K layout (D <= 4; lane half h owns dimensions h and h + 2):
+// VALU cost per pair: transcendental(s) + 1 FMA + ~0.7 (operand rebuild and reach flag,
+// amortised over the 128 sources of a group) ~ 5.7 issue slots against 11-12 for the difference
+// form.
+//
+// Build note: the library is compiled with -fno-slp-vectorize (Makefile).  With LLVM's SLP
+// vectoriser packing the two tiles' fp32 chains into v_pk_* pairs, the reach-gated version of
+// this kernel returned wrong, run-to-run varying sums for the ODD target tiles of a wave (the
+// second vector element) as soon as two tiles were gated; without SLP it is correct, bitwise
+// reproducible and faster (tests: test_matrix_core_kernels_reproducible_and_tile_count_independent).  K layout (D <= 4; lane half h owns dimensions h and h + 2):
 //   k 0..7   : dim 0 six partial products, |y'|^2_h * 1, |y'|^2_m * 1
 //   k 8..15  : dim 1 six partial products, |y'|^2_l * 1, 1 * |x''|^2_h
 //   k 16..23 : dim 2 six partial products, 1 * |x''|^2_m, 1 * |x''|^2_l
@@ -151,6 +157,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfast_kernel(const CfastArgs a)
       const unsigned char* lg = &lds[buf][g * CF_GROUP_BYTES];
       const cf32x4 cen = *reinterpret_cast<const cf32x4*>(lg);  // wave-uniform broadcast
       const float tau = *reinterpret_cast<const float*>(lg + 16);
+      const float reach2 = *reinterpret_cast<const float*>(lg + 20);  // (R_g + sqrt(tau_g))^2
+      // bit tt: some target of tile tt lies within reach of the group
+      unsigned near_mask = 0;
       const unsigned char* lrows = lg + CF_HDR;
       const float* lb = reinterpret_cast<const float*>(lg + CF_OFF_B);
       const cf32x4* lraw = reinterpret_cast<const cf32x4*>(lg + CF_OFF_RAW);
@@ -181,6 +190,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfast_kernel(const CfastArgs a)
         b1[4] = (__bf16)cm; b1[5] = (__bf16)ch; b1[6] = (__bf16)(h ? 0.f : sm); b1[7] = (__bf16)(h ? 0.f : sl);
         xb[tt][0] = b0;
         xb[tt][1] = b1;
+        // (finite and beyond reach, or the tile is searched: NaN / inf from non-finite coordinates
+        // must reach the exact branch, where they behave as in the reference)
+        near_mask |= (__ballot(!(sq > reach2 && sq <= 3.0e38f)) != 0ull ? 1u : 0u) << tt;
       }
 
 #pragma unroll 1
@@ -207,17 +219,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfast_kernel(const CfastArgs a)
           d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[0], xb[tt][0], d, 0, 0, 0);
           d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[1], xb[tt][1], d, 0, 0, 0);
 
-          // ---- rare branch: some pair of this tile is closer than the group radius allows
-          // (wave-uniform test on the minimum).  Such pairs get the exact difference form
-          // (bruteforce.py:53-54) from the fp32 coordinates; for 1/r the pair that carries the
-          // target's own index gets s = +inf, i.e. k = 0 (bruteforce.py:13-14).
-          float dmin = fminf(fminf(d[0], d[1]), d[2]);
+          // ---- rare branch.  A pair closer than sqrt(tau) needs its target within R_g + sqrt(tau) of
+          // the group's centre: the wave-uniform flag of this (target tile, group) skips the search
+          // for almost all tiles; where it is set, the minimum over the tile decides (wave-uniform
+          // again).  Such pairs get the exact difference form (bruteforce.py:53-54) from the fp32
+          // coordinates; for 1/r the pair that carries the target's own index gets s = +inf, i.e.
+          // k = 0 (bruteforce.py:13-14).
+          const bool gate = (near_mask >> tt) & 1u;
+          float dmin = INFINITY;
+          if (gate) {
+            dmin = fminf(fminf(d[0], d[1]), d[2]);
 #pragma unroll
-          for (int q = 3; q < 15; q += 2) dmin = fminf(fminf(dmin, d[q]), d[q + 1]);
-          dmin = fminf(dmin, d[15]);
+            for (int q = 3; q < 15; q += 2) dmin = fminf(fminf(dmin, d[q]), d[q + 1]);
+            dmin = fminf(dmin, d[15]);
+          }
           // (negated comparisons: a NaN -- non-finite coordinates poison a whole group's centre --
           // also takes the exact branch, where inf - x gives s = inf, k = 0 as in the reference)
-          if (__any(!(dmin > tau))) {
+          if (gate && __any(!(dmin > tau))) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
               if (!(d[q] > tau)) {

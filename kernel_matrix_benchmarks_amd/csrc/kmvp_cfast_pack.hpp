@@ -33,7 +33,7 @@ __global__ void cfast_morton_kernel(const float* __restrict__ y, const float* __
 }
 
 // One workgroup of CF_GROUP threads per group of sorted sources: centre = bounding-box midpoint of the
-// group in the caller's coordinates, rows y' = (y - c) * scale, tau = kappa * max |y'|^2, signal,
+// group in the caller's coordinates, rows y' = (y - c) * scale, tau = kappa * max |y'|^2, reach^2, signal,
 // the caller's fp32 coordinates, original global index.
 __global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
     const float* __restrict__ y, const float* __restrict__ b, const int* __restrict__ perm,
@@ -86,7 +86,9 @@ __global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
     float* hdr = reinterpret_cast<float*>(g);
     for (int d = 0; d < 4; ++d) hdr[d] = c[d];
     hdr[4] = CF_KAPPA * r2;
-    hdr[5] = hdr[6] = hdr[7] = 0.f;
+    const float reach = sqrtf(r2) + sqrtf(CF_KAPPA * r2);  // no pair below tau for targets farther than this from c
+    hdr[5] = reach * reach;
+    hdr[6] = hdr[7] = 0.f;
   }
   // row: k 0..7 dim 0 + (|y'|^2_h, |y'|^2_m); 8..15 dim 1 + (|y'|^2_l, 1); 16..23 dim 2 + (1, 1);
   //      24..31 dim 3 + (0, 0); then 8 bf16 of pad
