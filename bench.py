@@ -45,8 +45,8 @@ FLOPS_PER_PAIR = {"gaussian": 12, "inverse-distance": 12, "absolute-exponential"
 SLOTS_PER_PAIR = {
     "lowd_kernel": {"gaussian": 12, "inverse-distance": 11, "absolute-exponential": 16},
     "fast_kernel": {"gaussian": 5, "inverse-distance": 5, "absolute-exponential": 9},
-    # centred form: + ~0.7 operand rebuild + ~0.6 closest-pair test per pair
-    "cfast_kernel": {"gaussian": 6.3, "inverse-distance": 6.3, "absolute-exponential": 10.3},
+    # centred form: + ~0.7 per pair for the operand rebuild and the reach flag
+    "cfast_kernel": {"gaussian": 5.7, "inverse-distance": 5.7, "absolute-exponential": 9.7},
 }
 MFMA_FLOPS_PER_PAIR_FAST = 2 * 32  # two 32x32x16 bf16 k-steps (K = 6 D + 6 = 24 -> 32) for D = 3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
