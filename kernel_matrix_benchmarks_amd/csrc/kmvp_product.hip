@@ -94,6 +94,26 @@ __global__ void reduce_segments_kernel(const double* __restrict__ part, double* 
   sums[q] = v;
 }
 
+// One launch for the single-GPU epilogue: out[i*E + e] = sum over segments (index order) of
+// part[s][e][i], divided by the same sum of column E when normalised.  Same additions in the
+// same order as reduce_segments_kernel + finish_kernel.
+__global__ void reduce_finish_kernel(const double* __restrict__ part, double* __restrict__ out, int64_t n,
+                                     int64_t n_pad, int E, int NE, int segments, int normalise) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t count = (int64_t)NE * n_pad;
+  double den = 1.0;
+  if (normalise) {
+    den = 0.0;
+    for (int s = 0; s < segments; ++s) den += part[(int64_t)s * count + (int64_t)E * n_pad + i];
+  }
+  for (int e = 0; e < E; ++e) {
+    double v = 0.0;
+    for (int s = 0; s < segments; ++s) v += part[(int64_t)s * count + (int64_t)e * n_pad + i];
+    out[i * E + e] = normalise ? v / den : v;
+  }
+}
+
 // out[i*E + e] = sums[e][i]  (/ sums[E][i] when normalised)
 __global__ void finish_kernel(const double* __restrict__ sums, double* __restrict__ out, int64_t n,
                               int64_t n_pad, int E, int normalise) {
@@ -156,6 +176,32 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
   return KMVP_OK;
 }
 
+// Epilogue of the paths with fp64 partials [segment][column][n_pad] in c->part.  Without a
+// communicator one fused launch does it; with one, the segments are summed into c->sums first and
+// finish_product() exchanges them.
+int reduce_and_finish(kmvp_ctx* c, int segments, int NE, int64_t N, int64_t n_pad, int E, int sig) {
+  int rc;
+  const int64_t count = (int64_t)NE * n_pad;
+  if (c->comm) {
+    if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                       (const double*)c->part.p, (double*)c->sums.p, count, segments);
+    HIP_TRY(c, hipGetLastError());
+    return finish_product(c, count, N, n_pad, E, sig);
+  }
+  if ((rc = ensure(c, c->out, (size_t)std::max<int64_t>(N, 1) * E * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1))), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->out.p, N, n_pad, E, NE, segments, sig == SIG_NORM ? 1 : 0);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
+  HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
+  c->out_n = N;
+  c->out_e = E;
+  return KMVP_OK;
+}
+
 // Number of source segments of a launch (specialised kernels).  Three pulls:
 //  * L2 residency: with segments % 8 == 0 each XCD streams one segment at a time
 //    (block_to_work), so a segment of <= 2 MiB of records stays in its 4 MiB L2;
@@ -163,14 +209,14 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
 //    blocks (256 CUs x 8), which only matters when there are few target tiles;
 //  * the fp64 partial buffer segments * NE * n_pad * 8 bytes stays bounded.
 int choose_segments(const kmvp_ctx* c, int64_t tile_blocks, int64_t m_pad, int NE, int64_t n_pad,
-                    int64_t rec_bytes, int64_t min_seg) {
+                    int64_t rec_bytes, int64_t min_seg, bool small = false) {
   int64_t seg;
   if (c->opt_segments > 0) {
     seg = c->opt_segments;
   } else {
     const int64_t l2_seg_bytes = 2 << 20;
     seg = 8 * std::max<int64_t>(1, (m_pad * rec_bytes + 8 * l2_seg_bytes - 1) / (8 * l2_seg_bytes));
-    const int64_t target_blocks = 16384;
+    const int64_t target_blocks = small ? 4096 : 16384;  // small problems: about two rounds of resident blocks
     const int64_t for_parallelism = (target_blocks + tile_blocks - 1) / tile_blocks;
     if (for_parallelism > seg) seg = (for_parallelism + 7) / 8 * 8;
     const int64_t cap_len = std::max<int64_t>(1, m_pad / min_seg);              // segment >= min_seg sources
@@ -210,7 +256,9 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     const int64_t tile_blocks = n_pad / tile;
     const int64_t batch = 8;  // two ping-pong batches of 4 records
     const int64_t m_pad = round_up(std::max<int64_t>(M, 1), batch);
-    segments = choose_segments(c, tile_blocks, m_pad, NE, n_pad, (int64_t)R * sizeof(real), 1024);
+    // few targets: short segments, so that the launch still covers the chip (n = 2000, fp64: 121 -> 9 us)
+    const bool small = N < SMALL_PROBLEM_TARGETS;
+    segments = choose_segments(c, tile_blocks, m_pad, NE, n_pad, (int64_t)R * sizeof(real), small ? 32 : 1024, small);
     seg_len = round_up((m_pad + segments - 1) / segments, batch);
     segments = (int)((m_pad + seg_len - 1) / seg_len);
 
@@ -291,12 +339,7 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
 
   // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
-  const int64_t count = (int64_t)NE * n_pad;
-  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->sums.p, count, segments);
-  HIP_TRY(c, hipGetLastError());
-  return finish_product(c, count, N, n_pad, E, sig);
+  return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
 }
 
 // split-bf16 MFMA low-D path (kmvp_fast.hpp): float32, D <= 7, E == 1, selected by the
@@ -308,7 +351,10 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   const int EB = sig == SIG_DENSITY ? 0 : 1;
   const int64_t N = c->N, M = c->M;
   const int KS = fast_ksteps(D);
-  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : FAST_DEFAULT_TT;
+  // few targets (the reference's own datasets have n <= 1e4): one tile per wave and segments of a
+  // single stage spread the launch over more CUs; from ~3e4 targets on the big tiles win
+  const bool small = N < SMALL_PROBLEM_TARGETS;
+  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (small ? 1 : FAST_DEFAULT_TT);
   const int64_t SB = fast_stage_bytes(KS, EB);
   const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
@@ -319,7 +365,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   const int64_t m_stages = (m_tiles + FAST_STAGE - 1) / FAST_STAGE;
   int rc;
 
-  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, SB, 4);
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, SB, small ? 1 : 4, small);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
 
@@ -373,12 +419,8 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, le);
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
 
-  const int64_t count = (int64_t)NE * n_pad;
-  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->sums.p, count, segments);
-  HIP_TRY(c, hipGetLastError());
-  return finish_product(c, count, N, n_pad, E, sig);
+  // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
+  return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
 }
 
 // centred split-bf16 MFMA path (kmvp_cfast.hpp): float32, D <= 4, E == 1, every kernel.
@@ -388,7 +430,8 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   const int NE = sig == SIG_NORM ? 2 : 1;
   const int EB = sig == SIG_DENSITY ? 0 : 1;
   const int64_t N = c->N, M = c->M;
-  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : CFAST_DEFAULT_TT;
+  const bool small = N < SMALL_PROBLEM_TARGETS;  // see run_product_fast
+  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (small ? 1 : CFAST_DEFAULT_TT);
   const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   const int64_t tile = (int64_t)32 * TT * WAVES_PER_BLOCK;
@@ -400,7 +443,7 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   if (c->m_total > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "more than 2^31 sources");
   int rc;
 
-  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, CF_STAGE_BYTES, 4);
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, CF_STAGE_BYTES, small ? 1 : 4, small);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
 
@@ -471,12 +514,8 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, le);
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
 
-  const int64_t count = (int64_t)NE * n_pad;
-  if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->sums.p, count, segments);
-  HIP_TRY(c, hipGetLastError());
-  return finish_product(c, count, N, n_pad, E, sig);
+  // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
+  return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
 }
 
 // bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
