@@ -54,6 +54,20 @@ __global__ void cg_axpy_kernel(double* __restrict__ out, const double* __restric
   out[q] = u[q] + coef[q % E] * v[q];
 }
 
+// Coefficients of a vector update passed BY VALUE in the kernel argument block (E <= 8): no
+// host-to-device copy and no stream synchronisation per update (a small solve is otherwise
+// dominated by them: seven synchronisations per CG iteration instead of three).
+constexpr int COEF_INLINE_E = 8;
+struct Coef8 { double v[COEF_INLINE_E]; };
+struct Coef24 { double v[3 * COEF_INLINE_E]; };
+
+__global__ void cg_axpy_inline_kernel(double* __restrict__ out, const double* __restrict__ u,
+                                      const double* __restrict__ v, const Coef8 coef, int64_t m, int E) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * E) return;
+  out[q] = u[q] + coef.v[q % E] * v[q];
+}
+
 template <typename real>
 __global__ void cg_cast_kernel(const double* __restrict__ in, real* __restrict__ out, int64_t n) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,6 +98,13 @@ int cg_dots(kmvp_ctx* c, const double* u, const double* v, int64_t m, int E, con
 
 int cg_axpy(kmvp_ctx* c, double* out, const double* u, const double* v,
             const std::vector<double>& coef, int64_t m, int E, const CgWork& w) {
+  if (E <= COEF_INLINE_E) {
+    Coef8 k;
+    for (int e = 0; e < COEF_INLINE_E; ++e) k.v[e] = e < E ? coef[e] : 0.0;
+    hipLaunchKernelGGL(cg_axpy_inline_kernel, dim3(blocks_for(m * E)), dim3(256), 0, c->stream, out, u, v, k, m, E);
+    HIP_TRY(c, hipGetLastError());
+    return KMVP_OK;
+  }
   HIP_TRY(c, hipMemcpyAsync(w.coef, coef.data(), sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // coef is a host temporary
   hipLaunchKernelGGL(cg_axpy_kernel, dim3(blocks_for(m * E)), dim3(256), 0, c->stream, out, u, v,
@@ -224,6 +245,18 @@ __global__ void vec_lin3_kernel(double* __restrict__ out, const double* __restri
   out[q] = v;
 }
 
+__global__ void vec_lin3_inline_kernel(double* __restrict__ out, const double* __restrict__ a,
+                                       const double* __restrict__ b, const double* __restrict__ c,
+                                       const Coef24 coef, int64_t m, int E) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * E) return;
+  const int e = (int)(q % E);
+  double v = coef.v[e] * a[q];
+  if (b) v += coef.v[E + e] * b[q];
+  if (c) v += coef.v[2 * E + e] * c[q];
+  out[q] = v;
+}
+
 int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, int maxit,
                  double* out_b, int* iters, double* resid) {
   if (!c) return KMVP_E_INVALID;
@@ -245,6 +278,14 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
   wk.coef = wk.partial + (size_t)CG_BLOCKS * E;  // 3*E coefficients
   std::vector<double> hp((size_t)CG_BLOCKS * E), dots, coef(3 * (size_t)E);
   auto lin3 = [&](double* out, const double* pa, const double* pb, const double* pc) -> int {
+    if (E <= COEF_INLINE_E) {
+      Coef24 k;
+      for (int q = 0; q < 3 * COEF_INLINE_E; ++q) k.v[q] = q < 3 * E ? coef[q] : 0.0;
+      hipLaunchKernelGGL(vec_lin3_inline_kernel, dim3(blocks_for((int64_t)n)), dim3(256), 0, c->stream, out, pa, pb,
+                         pc, k, m, E);
+      HIP_TRY(c, hipGetLastError());
+      return KMVP_OK;
+    }
     HIP_TRY(c, hipMemcpyAsync(wk.coef, coef.data(), sizeof(double) * 3 * E, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipLaunchKernelGGL(vec_lin3_kernel, dim3(blocks_for((int64_t)n)), dim3(256), 0, c->stream, out, pa, pb, pc,
