@@ -183,6 +183,41 @@ def test_clusters_far_apart_and_non_finite_points():
             assert rel_err(np.delete(got, 5, axis=0), np.delete(want, 5, axis=0)) <= TOL32, (kernel, extra["device_kernel"])
 
 
+def test_random_shapes_flags_and_precisions():
+    """Seeded sweep over shapes the golden set does not hold: every dispatch decision (difference /
+    global-centre / per-group-centre / generic kernels, small-problem launch shapes, ragged tiles,
+    x == y and x != y, all query() branches) against the numpy oracle."""
+    rs = np.random.RandomState(20240607)
+    for case_no in range(72):
+        kernel = golden_cases.KERNELS[case_no % 3]
+        D = int(rs.choice([1, 2, 3, 3, 3, 4, 5, 8, 9, 17]))
+        E = int(rs.choice([1, 1, 1, 2, 4, 5]))
+        M = int(rs.choice([1, 31, 33, 127, 129, 257, 700, 1500]))
+        same = bool(rs.rand() < 0.5)
+        N = M if same else int(rs.choice([1, 32, 65, 255, 513, 900]))
+        norm = bool(rs.rand() < 0.4)
+        dens = bool(rs.rand() < 0.2)
+        prec = "float64" if rs.rand() < 0.35 else "float32"
+        spread = float(rs.choice([1.0, 1.0, 6.0]))  # 6: scaled radius beyond the global-centre rule
+        y = rs.rand(M, D) * spread
+        x = None if same else rs.rand(N, D) * spread
+        b = None if dens else rs.randn(M, E)
+        if prec == "float32":  # the backend is handed float32 inputs: the oracle gets the same numbers
+            y = y.astype(np.float32).astype(np.float64)
+            x = None if x is None else x.astype(np.float32).astype(np.float64)
+            b = None if b is None else b.astype(np.float32).astype(np.float64)
+        want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b,
+                                   normalize_rows=norm, density_estimation=dens)
+        case = dict(kernel=kernel, D=D, normalize_rows=norm)
+        got, extra = run_plugin(case, y, x, b, prec)
+        assert got.shape == want.shape, (case_no, got.shape, want.shape)
+        fin = np.isfinite(want).all(axis=-1)
+        assert np.array_equal(np.isfinite(got).all(axis=-1), fin), (case_no, kernel, extra)
+        tol = TOL64 if prec == "float64" else 2e-5
+        assert rel_err(got, want) <= tol, (case_no, kernel, D, E, N, M, same, norm, dens, prec, extra["device_kernel"],
+                                          rel_err(got, want))
+
+
 def test_matrix_core_kernels_reproducible_and_tile_count_independent():
     """LDS-DMA staged kernels must not depend on timing: bitwise identical results run to run at a
     size where every CU is busy, and the same sums (to float32 rounding) whatever the number of
