@@ -479,12 +479,13 @@ __global__ void pack_targets_kernel(const real* __restrict__ x, real* __restrict
 template <typename real>
 __global__ void pack_sources_kernel(const real* __restrict__ y, const real* __restrict__ b,
                                     real* __restrict__ rec, int64_t m, int64_t m_pad, int D, int EB,
-                                    int R, real scale) {
+                                    int R, real scale, int ldb = -1, int col0 = 0) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m_pad) return;
+  if (ldb < 0) ldb = EB;  // the signal has exactly EB columns; otherwise columns col0 .. col0+EB of ldb
   real* r = rec + j * R;
   for (int d = 0; d < D; ++d) r[d] = j < m ? y[j * D + d] * scale : (real)INFINITY;
-  for (int e = 0; e < EB; ++e) r[D + e] = j < m ? b[j * EB + e] : (real)0;
+  for (int e = 0; e < EB; ++e) r[D + e] = j < m ? b[j * ldb + col0 + e] : (real)0;
   for (int q = D + EB; q < R; ++q) r[q] = (real)0;
 }
 

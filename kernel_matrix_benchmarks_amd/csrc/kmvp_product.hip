@@ -114,6 +114,20 @@ __global__ void reduce_finish_kernel(const double* __restrict__ part, double* __
   }
 }
 
+// Column-blocked products: block partials part[s][e][i] (e < NEk) summed over the segments into the
+// full sums array: column e < Ek goes to col0 + e, the extra column (denominator) to den_col.
+__global__ void reduce_block_kernel(const double* __restrict__ part, double* __restrict__ sums, int64_t n_pad,
+                                    int NEk, int Ek, int segments, int col0, int den_col) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t count = (int64_t)NEk * n_pad;
+  if (q >= count) return;
+  const int e = (int)(q / n_pad);
+  const int64_t i = q % n_pad;
+  double v = 0.0;
+  for (int s = 0; s < segments; ++s) v += part[(int64_t)s * count + q];
+  sums[(int64_t)(e < Ek ? col0 + e : den_col) * n_pad + i] = v;
+}
+
 // out[i*E + e] = sums[e][i]  (/ sums[E][i] when normalised)
 __global__ void finish_kernel(const double* __restrict__ sums, double* __restrict__ out, int64_t n,
                               int64_t n_pad, int E, int normalise) {
@@ -340,6 +354,86 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
 
   // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
   return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
+}
+
+// Low D, many signal columns (D <= LOWD_MAX_D, E > LOWD_MAX_E): the specialised pair loop run
+// once per block of LOWD_MAX_E columns (the kernel values are recomputed per block: E = 16 costs
+// four passes of 14 issue slots per pair, against a generic kernel that is 4-5x slower).  The
+// denominator of normalised rows comes from the first block.
+template <typename real>
+int run_product_blocked(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D, E = c->E;
+  const int NE = sig == SIG_NORM ? E + 1 : E;
+  const int64_t N = c->N, M = c->M;
+  const real* x_raw = (const real*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  int rc;
+  LowdTuning tune;
+  tune.feed = DEFAULT_FEED;
+  tune.targets_per_lane = DEFAULT_TARGETS_PER_LANE;
+  const int T = tune.targets_per_lane;
+  const int R = (D + LOWD_MAX_E + 3) / 4 * 4;
+  const int64_t tile = 64 * (int64_t)T * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(std::max<int64_t>(N, 1), tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t batch = 8;
+  const int64_t m_pad = round_up(std::max<int64_t>(M, 1), batch);
+  const bool small = N < SMALL_PROBLEM_TARGETS;
+  int segments = choose_segments(c, tile_blocks, m_pad, LOWD_MAX_E + 1, n_pad, (int64_t)R * sizeof(real),
+                                 small ? 32 : 1024, small);
+  const int64_t seg_len = round_up((m_pad + segments - 1) / segments, batch);
+  segments = (int)((m_pad + seg_len - 1) / seg_len);
+
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                         c->packed_layout != LAYOUT_LOWD || c->packed_T != T;
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)D * n_pad * sizeof(real)))) return rc;
+    hipLaunchKernelGGL((pack_targets_kernel<real>), dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
+                       (real*)c->xs.p, N, n_pad, D, (real)1);
+  }
+  c->packed_points_ver = c->points_ver;
+  c->packed_kernel = kernel;
+  c->packed_layout = LAYOUT_LOWD;
+  c->packed_T = T;
+  c->packed_sig = -1;  // the source records below hold one column block: never reusable as they are
+  if ((rc = ensure(c, c->rec, (size_t)(m_pad + batch) * R * sizeof(real)))) return rc;
+  if ((rc = ensure(c, c->part, (size_t)segments * (LOWD_MAX_E + 1) * n_pad * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->sums, (size_t)NE * n_pad * sizeof(double)))) return rc;
+
+  const int64_t nblocks = tile_blocks * segments;
+  if (nblocks > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  for (int e0 = 0; e0 < E; e0 += LOWD_MAX_E) {
+    const int Ek = std::min(LOWD_MAX_E, E - e0);
+    const int sigk = (sig == SIG_NORM && e0 == 0) ? SIG_NORM : SIG_PRODUCT;
+    const int NEk = sigk == SIG_NORM ? Ek + 1 : Ek;
+    const int Rk = (D + Ek + 3) / 4 * 4;
+    hipLaunchKernelGGL((pack_sources_kernel<real>), dim3(blocks_for(m_pad + batch)), dim3(256), 0, c->stream,
+                       (const real*)c->y_raw.p, (const real*)c->b_raw.p, (real*)c->rec.p, M, m_pad + batch, D, Ek,
+                       Rk, (real)1, E, e0);
+    LowdArgs<real> a;
+    a.xs = (const real*)c->xs.p;
+    a.rec = (const real*)c->rec.p;
+    a.part = (double*)c->part.p;
+    a.n = N;
+    a.n_pad = n_pad;
+    a.m_pad = m_pad;
+    a.seg_len = seg_len;
+    a.segments = segments;
+    a.tile_blocks = (int)tile_blocks;
+    a.chunk = (int)round_up(std::max(c->opt_chunk, 8), batch);
+    a.j_offset = c->j_offset;
+    a.m_total = c->m_total;
+    hipError_t le = launch_lowd<real>(kernel, D, Ek, sigk, tune, a, dim3((unsigned)nblocks), c->stream,
+                                      &c->last_kernel_name);
+    if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "no kernel instantiated for this column block");
+    HIP_TRY(c, le);
+    hipLaunchKernelGGL(reduce_block_kernel, dim3(blocks_for((int64_t)NEk * n_pad)), dim3(256), 0, c->stream,
+                       (const double*)c->part.p, (double*)c->sums.p, n_pad, NEk, Ek, segments, e0, E);
+    HIP_TRY(c, hipGetLastError());
+  }
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
 }
 
 // split-bf16 MFMA low-D path (kmvp_fast.hpp): float32, D <= 7, E == 1, selected by the
@@ -699,6 +793,8 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     if (c->opt_fast == 1 || (c->opt_fast < 0 && global_ok)) return run_product_fast(c, kernel, sig);
     if (centred_ok && (c->opt_fast == 2 || c->opt_fast < 0)) return run_product_cfast(c, kernel, sig);
   }
+  if (c->D <= LOWD_MAX_D && !c->density && c->E > LOWD_MAX_E)  // low D, many signal columns
+    return c->dtype == KMVP_F64 ? run_product_blocked<double>(c, kernel, sig) : run_product_blocked<float>(c, kernel, sig);
   if (c->dtype == KMVP_F64) return run_product_t<double>(c, kernel, sig);
   return run_product_t<float>(c, kernel, sig);
 }
