@@ -52,7 +52,7 @@ __host__ __device__ constexpr int fast_stage_bytes(int KS, int EB) {
   return (FAST_STAGE * fast_tile_bytes(KS, EB) + 4095) / 4096 * 4096;
 }
 
-__host__ __device__ constexpr int fast_target_row(int D) { return D <= 3 ? 4 : 8; }  // floats per target
+__host__ __device__ constexpr int fast_target_row(int D) { return (D + 1 + 3) / 4 * 4; }  // floats per target
 
 struct FastArgs {
   const float* xr;           // targets [n_pad][fast_target_row(D)]: centred scaled coordinates, then |x'|^2
@@ -151,8 +151,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fast_kernel(const FastArgs a) {
   const int h = lane >> 5;
   const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;  // first target tile of the wave
 
-  // The B operand of this lane's targets is built in registers from 4 (D <= 3) or 8 floats per
-  // target; a pre-packed operand array would be 16 KS bf16 per target, re-read once per source
+  // The B operand of this lane's targets is built in registers from D + 1 floats per target
+  // (rounded up to whole float4s); a pre-packed operand array would be 16 KS bf16 per target, re-read once per source
   // segment (at the headline shape 3 GB of L2 fills per launch instead of 0.8 GB).
   bf16x8 xb[TT][KS];
   int64_t jz[TT];

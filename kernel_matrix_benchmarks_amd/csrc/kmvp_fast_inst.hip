@@ -21,7 +21,10 @@ static hipError_t launch_tt(int TT, const FastArgs& args, dim3 grid, hipStream_t
   switch (TT) {
     case 1: return launch_one<D, SIG, 1>(args, grid, stream);
     case 2: return launch_one<D, SIG, 2>(args, grid, stream);
-    case 4: return launch_one<D, SIG, 4>(args, grid, stream);
+    case 4:
+      // four tiles per wave only where the operands fit the register file (K = 6 D + 6 <= 48)
+      if constexpr (D <= FAST_MAX_D_FOUR_TILES) return launch_one<D, SIG, 4>(args, grid, stream);
+      return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }
@@ -47,6 +50,22 @@ hipError_t KMVP_FN(int D, int sig, int TT, const FastArgs& args, dim3 grid, hipS
     case 5: return launch_sig<5>(sig, TT, args, grid, stream);
     case 6: return launch_sig<6>(sig, TT, args, grid, stream);
     case 7: return launch_sig<7>(sig, TT, args, grid, stream);
+    case 8: return launch_sig<8>(sig, TT, args, grid, stream);
+    case 9: return launch_sig<9>(sig, TT, args, grid, stream);
+    case 10: return launch_sig<10>(sig, TT, args, grid, stream);
+    case 11: return launch_sig<11>(sig, TT, args, grid, stream);
+    case 12: return launch_sig<12>(sig, TT, args, grid, stream);
+    case 13: return launch_sig<13>(sig, TT, args, grid, stream);
+    case 14: return launch_sig<14>(sig, TT, args, grid, stream);
+    case 15: return launch_sig<15>(sig, TT, args, grid, stream);
+    case 16: return launch_sig<16>(sig, TT, args, grid, stream);
+    case 17: return launch_sig<17>(sig, TT, args, grid, stream);
+    case 18: return launch_sig<18>(sig, TT, args, grid, stream);
+    case 19: return launch_sig<19>(sig, TT, args, grid, stream);
+    case 20: return launch_sig<20>(sig, TT, args, grid, stream);
+    case 21: return launch_sig<21>(sig, TT, args, grid, stream);
+    case 22: return launch_sig<22>(sig, TT, args, grid, stream);
+    case 23: return launch_sig<23>(sig, TT, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }

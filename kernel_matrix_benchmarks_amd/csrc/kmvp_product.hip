@@ -448,7 +448,8 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   // few targets (the reference's own datasets have n <= 1e4): one tile per wave and segments of a
   // single stage spread the launch over more CUs; from ~3e4 targets on the big tiles win
   const bool small = N < SMALL_PROBLEM_TARGETS;
-  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (small ? 1 : FAST_DEFAULT_TT);
+  const int TT = c->opt_fast_tiles > 0 ? (D > FAST_MAX_D_FOUR_TILES ? std::min(c->opt_fast_tiles, 2) : c->opt_fast_tiles)
+                                       : (small ? 1 : (D > FAST_MAX_D_FOUR_TILES ? 2 : FAST_DEFAULT_TT));
   const int64_t SB = fast_stage_bytes(KS, EB);
   const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
