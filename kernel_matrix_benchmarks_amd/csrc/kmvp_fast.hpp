@@ -41,7 +41,8 @@ namespace kmvp {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FAST_TILE = 32;   // sources per tile = targets per result column block
-constexpr int FAST_STAGE = 4;   // source tiles per LDS stage
+// source tiles per LDS stage: four while a stage stays below ~40 KiB (K <= 144), two beyond
+__host__ __device__ constexpr int fast_stage_tiles(int KS) { return KS <= 9 ? 4 : 2; }
 
 __host__ __device__ constexpr int fast_ksteps(int D) { return (6 * D + 6 + 15) / 16; }
 __host__ __device__ constexpr int fast_row_bytes(int KS) { return KS * 32 + 16; }  // padded source row
@@ -49,7 +50,7 @@ __host__ __device__ constexpr int fast_tile_bytes(int KS, int EB) {
   return FAST_TILE * fast_row_bytes(KS) + FAST_TILE * 4 * (EB > 0 ? EB : 0);
 }
 __host__ __device__ constexpr int fast_stage_bytes(int KS, int EB) {
-  return (FAST_STAGE * fast_tile_bytes(KS, EB) + 4095) / 4096 * 4096;
+  return (fast_stage_tiles(KS) * fast_tile_bytes(KS, EB) + 4095) / 4096 * 4096;
 }
 
 __host__ __device__ constexpr int fast_target_row(int D) { return (D + 1 + 3) / 4 * 4; }  // floats per target
@@ -60,7 +61,7 @@ struct FastArgs {
   double* part;              // partial sums [segments][NE][n_pad]
   int64_t n_pad;
   int64_t m_tiles;           // source tiles of 32
-  int64_t m_stages;          // source stages of FAST_STAGE tiles
+  int64_t m_stages;          // source stages of fast_stage_tiles(KS) tiles
   int64_t seg_stages;        // stages per segment
   int segments;
   int tile_blocks;
@@ -222,9 +223,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fast_kernel(const FastArgs a) {
     const int buf = (int)((s - s_begin) & 1);
     if (s + 1 < s_end) stage_in(s + 1, buf ^ 1);
 #pragma unroll 1
-    for (int q = 0; q < FAST_STAGE; ++q) {
+    for (int q = 0; q < fast_stage_tiles(KS); ++q) {
       const unsigned char* lt = &lds[buf][q * TB];
-      const int64_t t = s * FAST_STAGE + q;  // source tile index (tiles beyond m_tiles are all-pad)
+      const int64_t t = s * fast_stage_tiles(KS) + q;  // source tile index (tiles beyond m_tiles are all-pad)
       // A fragments of the tile (row r, 8 consecutive k per k-step) and the 16 signal values
       // of this lane's rows: registers 4g..4g+3 hold rows 8g+4h .. 8g+4h+3
       bf16x8 ya[KS];

@@ -20,7 +20,9 @@ template <int D, int SIG>
 static hipError_t launch_tt(int TT, const FastArgs& args, dim3 grid, hipStream_t stream) {
   switch (TT) {
     case 1: return launch_one<D, SIG, 1>(args, grid, stream);
-    case 2: return launch_one<D, SIG, 2>(args, grid, stream);
+    case 2:
+      if constexpr (D <= FAST_MAX_D_TWO_TILES) return launch_one<D, SIG, 2>(args, grid, stream);
+      return hipErrorInvalidValue;
     case 4:
       // four tiles per wave only where the operands fit the register file (K = 6 D + 6 <= 48)
       if constexpr (D <= FAST_MAX_D_FOUR_TILES) return launch_one<D, SIG, 4>(args, grid, stream);
@@ -66,6 +68,22 @@ hipError_t KMVP_FN(int D, int sig, int TT, const FastArgs& args, dim3 grid, hipS
     case 21: return launch_sig<21>(sig, TT, args, grid, stream);
     case 22: return launch_sig<22>(sig, TT, args, grid, stream);
     case 23: return launch_sig<23>(sig, TT, args, grid, stream);
+    case 24: return launch_sig<24>(sig, TT, args, grid, stream);
+    case 25: return launch_sig<25>(sig, TT, args, grid, stream);
+    case 26: return launch_sig<26>(sig, TT, args, grid, stream);
+    case 27: return launch_sig<27>(sig, TT, args, grid, stream);
+    case 28: return launch_sig<28>(sig, TT, args, grid, stream);
+    case 29: return launch_sig<29>(sig, TT, args, grid, stream);
+    case 30: return launch_sig<30>(sig, TT, args, grid, stream);
+    case 31: return launch_sig<31>(sig, TT, args, grid, stream);
+    case 32: return launch_sig<32>(sig, TT, args, grid, stream);
+    case 33: return launch_sig<33>(sig, TT, args, grid, stream);
+    case 34: return launch_sig<34>(sig, TT, args, grid, stream);
+    case 35: return launch_sig<35>(sig, TT, args, grid, stream);
+    case 36: return launch_sig<36>(sig, TT, args, grid, stream);
+    case 37: return launch_sig<37>(sig, TT, args, grid, stream);
+    case 38: return launch_sig<38>(sig, TT, args, grid, stream);
+    case 39: return launch_sig<39>(sig, TT, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -82,9 +82,10 @@ __global__ void pack_fast_sources_kernel(const float* __restrict__ y, const floa
                                          const float* __restrict__ centre, unsigned char* __restrict__ img,
                                          int64_t m, int64_t m_stages, int D, int EB, int KS, float scale) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m_stages * FAST_STAGE * FAST_TILE) return;
-  const int64_t stage = j / (FAST_STAGE * FAST_TILE);
-  const int q = (int)((j / FAST_TILE) % FAST_STAGE);
+  const int ST = fast_stage_tiles(KS);
+  if (j >= m_stages * ST * FAST_TILE) return;
+  const int64_t stage = j / (ST * FAST_TILE);
+  const int q = (int)((j / FAST_TILE) % ST);
   const int r = (int)(j % FAST_TILE);
   const int RB = fast_row_bytes(KS);
   unsigned char* tile = img + stage * (int64_t)fast_stage_bytes(KS, EB) + q * fast_tile_bytes(KS, EB);

@@ -54,8 +54,9 @@ hipError_t launch_mfma_invdist(int KS, int NT, int TW, const MfmaArgs& args, dim
 
 
 // split-bf16 MFMA low-D path (kmvp_fast.hpp): 6 D + 6 <= 48, E == 1
-constexpr int FAST_MAX_D = 23;             // K = 6 D + 6 <= 144 = 9 k-steps of 16
+constexpr int FAST_MAX_D = 39;             // K = 6 D + 6 <= 240 = 15 k-steps of 16
 constexpr int FAST_MAX_D_FOUR_TILES = 7;  // four target tiles per wave up to K = 48
+constexpr int FAST_MAX_D_TWO_TILES = 23;  // two up to K = 144, one beyond
 constexpr int FAST_DEFAULT_TT = 4;
 // auto mode: scaled squared radius of the clouds below which the expansion is used
 constexpr float FAST_AUTO_RADIUS2 = 8.0f;

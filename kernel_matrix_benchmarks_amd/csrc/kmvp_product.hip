@@ -448,8 +448,8 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   // few targets (the reference's own datasets have n <= 1e4): one tile per wave and segments of a
   // single stage spread the launch over more CUs; from ~3e4 targets on the big tiles win
   const bool small = N < SMALL_PROBLEM_TARGETS;
-  const int TT = c->opt_fast_tiles > 0 ? (D > FAST_MAX_D_FOUR_TILES ? std::min(c->opt_fast_tiles, 2) : c->opt_fast_tiles)
-                                       : (small ? 1 : (D > FAST_MAX_D_FOUR_TILES ? 2 : FAST_DEFAULT_TT));
+  const int tt_max = D > FAST_MAX_D_TWO_TILES ? 1 : (D > FAST_MAX_D_FOUR_TILES ? 2 : 4);  // what is instantiated
+  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, tt_max) : (small ? 1 : std::min(FAST_DEFAULT_TT, tt_max));
   const int64_t SB = fast_stage_bytes(KS, EB);
   const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
@@ -457,7 +457,8 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   const int64_t n_pad = round_up(N, tile);
   const int64_t tile_blocks = n_pad / tile;
   const int64_t m_tiles = (M + FAST_TILE - 1) / FAST_TILE;
-  const int64_t m_stages = (m_tiles + FAST_STAGE - 1) / FAST_STAGE;
+  const int ST = fast_stage_tiles(KS);
+  const int64_t m_stages = (m_tiles + ST - 1) / ST;
   int rc;
 
   int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, SB, small ? 1 : 4, small);
@@ -476,7 +477,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   }
   if (sig_stale) {
     if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
-    hipLaunchKernelGGL(pack_fast_sources_kernel, dim3(blocks_for(m_stages * FAST_STAGE * FAST_TILE)),
+    hipLaunchKernelGGL(pack_fast_sources_kernel, dim3(blocks_for(m_stages * ST * FAST_TILE)),
                        dim3(256), 0, c->stream, (const float*)c->y_raw.p, (const float*)c->b_raw.p, centre,
                        (unsigned char*)c->rec.p, M, m_stages, D, EB, KS, scale);
   }
@@ -499,7 +500,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   a.seg_stages = seg_stages;
   a.segments = segments;
   a.tile_blocks = (int)tile_blocks;
-  a.chunk_stages = std::max(1, c->opt_chunk / (FAST_TILE * FAST_STAGE));
+  a.chunk_stages = std::max(1, c->opt_chunk / (FAST_TILE * ST));
   a.j_offset = c->j_offset;
   a.m_total = c->m_total;
   const dim3 grid((unsigned)(tile_blocks * segments));

@@ -190,7 +190,7 @@ def test_random_shapes_flags_and_precisions():
     rs = np.random.RandomState(20240607)
     for case_no in range(72):
         kernel = golden_cases.KERNELS[case_no % 3]
-        D = int(rs.choice([1, 2, 3, 3, 3, 4, 5, 8, 9, 12, 17, 23, 24]))
+        D = int(rs.choice([1, 2, 3, 3, 3, 4, 5, 8, 9, 12, 17, 23, 24, 39, 40]))
         E = int(rs.choice([1, 1, 1, 2, 4, 5]))
         M = int(rs.choice([1, 31, 33, 127, 129, 257, 700, 1500]))
         same = bool(rs.rand() < 0.5)
