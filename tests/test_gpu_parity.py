@@ -199,8 +199,9 @@ def test_random_shapes_flags_and_precisions():
         dens = bool(rs.rand() < 0.2)
         prec = "float64" if rs.rand() < 0.35 else "float32"
         spread = float(rs.choice([1.0, 1.0, 6.0]))  # 6: scaled radius beyond the global-centre rule
-        y = rs.rand(M, D) * spread
-        x = None if same else rs.rand(N, D) * spread
+        scale = spread / np.sqrt(max(D, 3) / 3.0)  # typical squared distances stay O(spread^2): no float32 underflow
+        y = rs.rand(M, D) * scale
+        x = None if same else rs.rand(N, D) * scale
         b = None if dens else rs.randn(M, E)
         if prec == "float32":  # the backend is handed float32 inputs: the oracle gets the same numbers
             y = y.astype(np.float32).astype(np.float64)
