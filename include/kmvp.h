@@ -130,11 +130,12 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
 
 /* BaseAlgorithm.set_query_arguments (base.py:40-42): tuning knobs, all optional.
  *   "feed"             -1 = auto (default), 0 = scalar-cache source stream, 1 = LDS-staged tiles
- *   "targets_per_lane" 0 = auto (default), 1, 2, 4 or 8
+ *   "targets_per_lane" 0 = auto (default), 1, 2, 4 or 8 (difference form); bf16 path: 1 or 2 target
+ *                      tiles per wavefront without software pipelining, 0 = pipelined where instantiated
  *   "segments"         number of source segments a launch is split into (0 = auto)
  *   "chunk"            sources summed in fp32 before folding into the fp64 sum
  *   "fast_sqdists"     squared distances in the expanded form |x|^2+|y|^2-2x.y on the matrix
- *                      cores (bruteforce.py:36-49 `fast_sqdists`; float32, D <= 7, E == 1):
+ *                      cores (bruteforce.py:36-49 `fast_sqdists`; float32, D <= 39, E == 1):
  *                      1 = always, around one centre for the whole cloud (fast_kernel);
  *                      2 = always, around per-group centres of Morton-sorted sources with exact
  *                          recomputation of the closest pairs (cfast_kernel, D <= 4);
@@ -144,7 +145,8 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  *                          radius, else 2 where it applies
  *   "same_points_global" 1 when the targets passed to kmvp_set_points are the unsharded
  *                      sources (sharded same_points): enables form 2 for inverse-distance
- *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4 */
+ *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4
+ *                      (clamped to what is instantiated: 4 up to D = 7, 2 up to D = 23, 1 beyond) */
 int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);
 
 /* BaseAlgorithm.get_memory_usage / get_additional (base.py:35-46): bytes of device
