@@ -99,6 +99,7 @@ struct kmvp_ctx {
   int64_t M = 0, N = 0, j_offset = 0, m_total = 0;
   bool same_points = false;
   bool have_points = false, have_signal = false, density = false;
+  bool async_product = false;   // solvers: run_product() leaves the result on the stream, no host synchronisation
 
   DevBuf y_raw, x_raw, b_raw;   // caller's arrays in the working precision
   DevBuf xs, rec;               // kernel layouts (specialised path; bf16 path: augmented targets, tile images)

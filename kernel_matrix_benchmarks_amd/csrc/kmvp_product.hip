@@ -181,12 +181,13 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
   hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1))), dim3(256), 0, c->stream,
                      sums, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0);
   HIP_TRY(c, hipGetLastError());
+  c->out_n = N;
+  c->out_e = E;
+  if (c->async_product) return KMVP_OK;  // the caller keeps working on the stream
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
-  c->out_n = N;
-  c->out_e = E;
   return KMVP_OK;
 }
 
@@ -207,12 +208,13 @@ int reduce_and_finish(kmvp_ctx* c, int segments, int NE, int64_t N, int64_t n_pa
   hipLaunchKernelGGL(reduce_finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1))), dim3(256), 0, c->stream,
                      (const double*)c->part.p, (double*)c->out.p, N, n_pad, E, NE, segments, sig == SIG_NORM ? 1 : 0);
   HIP_TRY(c, hipGetLastError());
+  c->out_n = N;
+  c->out_e = E;
+  if (c->async_product) return KMVP_OK;  // the caller keeps working on the stream
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
-  c->out_n = N;
-  c->out_e = E;
   return KMVP_OK;
 }
 

@@ -79,6 +79,66 @@ __global__ void cg_widen_kernel(const real* __restrict__ in, double* __restrict_
   if (q < n) out[q] = (double)in[q];
 }
 
+constexpr int CG_CHECK = 8;  // iterations between two looks at the residual on the host
+
+// One block.  mode 1: pAp[e] = sum of the partials -> alpha[e] = rs_old[e] / pAp[e];
+// mode 2: rs_new[e] = sum -> beta[e] = rs_new[e] / rs_old[e], rs_old[e] = rs_new[e], iteration count + 1,
+// and the stopping test max_e sqrt(rs_new / |a|^2) <= rtol: once it holds, `stop` is set and every
+// later kernel of the burst returns at once, so the iterate the host reads is the one of the FIRST
+// iteration that met the tolerance (the residual of an ill-conditioned system does not fall
+// monotonically: at config 5 it meets 1e-6 at iteration 132 and not again before 240).
+// scal = [rs_old | alpha | beta | |a|^2] x E, then stop, iterations.  Partials are added in block
+// order, as the host would.
+__global__ void cg_scalars_kernel(const double* __restrict__ partial, double* __restrict__ scal, int E, int mode,
+                                  double rtol) {
+  double* stop = scal + 4 * E;
+  if (*stop != 0.0) return;
+  __shared__ int not_met;
+  if (threadIdx.x == 0) not_met = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    double v = 0.0;
+    for (int b = 0; b < CG_BLOCKS; ++b) v += partial[(int64_t)b * E + e];
+    const double rs_old = scal[e];
+    if (mode == 1) {
+      scal[E + e] = (v != 0.0 && rs_old > 0.0) ? rs_old / v : 0.0;
+    } else {
+      scal[2 * E + e] = rs_old > 0.0 ? v / rs_old : 0.0;
+      scal[e] = v;
+      const double a2 = scal[3 * E + e];
+      if (a2 > 0.0 && sqrt(v / a2) > rtol) atomicOr(&not_met, 1);
+    }
+  }
+  if (mode == 2) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      scal[4 * E + 1] += 1.0;
+      if (!not_met) *stop = 1.0;
+    }
+  }
+}
+
+// x += alpha p ; r -= alpha Ap
+__global__ void cg_update_xr_kernel(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                                    const double* __restrict__ Ap, const double* __restrict__ scal, int64_t m,
+                                    int E) {
+  if (scal[4 * E] != 0.0) return;  // stopped
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * E) return;
+  const double a = scal[E + q % E];
+  x[q] = x[q] + a * p[q];
+  r[q] = r[q] + (-a) * Ap[q];
+}
+
+// p = r + beta p
+__global__ void cg_update_p_kernel(double* __restrict__ p, const double* __restrict__ r,
+                                   const double* __restrict__ scal, int64_t m, int E) {
+  if (scal[4 * E] != 0.0) return;  // stopped
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * E) return;
+  p[q] = r[q] + scal[2 * E + q % E] * p[q];
+}
+
 struct CgWork {
   double *x, *r, *p, *partial, *coef;
 };
@@ -147,7 +207,7 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t m = c->N;  // length of the Krylov vectors: all points
   const size_t vec = (size_t)m * E * sizeof(double);
-  int rc = ensure(c, c->scratch, 3 * vec + sizeof(double) * (CG_BLOCKS + 1) * E);
+  int rc = ensure(c, c->scratch, 3 * vec + sizeof(double) * ((CG_BLOCKS + 1 + 4) * (size_t)E + 2));
   if (rc) return rc;
   CgWork w;
   w.x = (double*)c->scratch.p;
@@ -181,23 +241,54 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
     return wv;
   };
 
+  // ---- the iteration lives on the device: the step lengths are computed by one-block kernels from
+  // the dot products' partial sums (same additions in the same order as the host would do) and the
+  // vector updates read them from device memory, so an iteration is a sequence of launches with no
+  // host synchronisation; the host looks at the residual every CG_CHECK iterations only.
+  double* scal = w.partial + (size_t)CG_BLOCKS * E + E;  // [rs_old | alpha | beta | |a|^2] x E, stop, iterations
+  {
+    std::vector<double> init((size_t)4 * E + 2, 0.0);
+    for (int e = 0; e < E; ++e) {
+      init[e] = rs[e];
+      init[3 * E + e] = anorm2[e];
+    }
+    HIP_TRY(c, hipMemcpyAsync(scal, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  const unsigned vblocks = blocks_for(m * E);
+  std::vector<double> state((size_t)4 * E + 2);
   int it = 0;
   double rel = worst(rs);
+  c->async_product = true;
   while (it < maxit && rel > rtol) {
-    if ((rc = cg_apply(c, kernel, w.p, m, E))) return rc;
-    const double* Ap = (const double*)c->out.p;
-    if ((rc = cg_dots(c, w.p, Ap, m, E, w, hp, pap))) return rc;
-    for (int e = 0; e < E; ++e) coef[e] = (pap[e] != 0.0 && rs[e] > 0.0) ? rs[e] / pap[e] : 0.0;
-    if ((rc = cg_axpy(c, w.x, w.x, w.p, coef, m, E, w))) return rc;
-    for (int e = 0; e < E; ++e) coef[e] = -coef[e];
-    if ((rc = cg_axpy(c, w.r, w.r, Ap, coef, m, E, w))) return rc;
-    if ((rc = cg_dots(c, w.r, w.r, m, E, w, hp, rs_new))) return rc;
-    for (int e = 0; e < E; ++e) coef[e] = rs[e] > 0.0 ? rs_new[e] / rs[e] : 0.0;
-    if ((rc = cg_axpy(c, w.p, w.r, w.p, coef, m, E, w))) return rc;
-    rs = rs_new;
+    const int burst = std::min(CG_CHECK, maxit - it);
+    for (int k = 0; k < burst; ++k) {
+      if ((rc = cg_apply(c, kernel, w.p, m, E))) {
+        c->async_product = false;
+        return rc;
+      }
+      const double* Ap = (const double*)c->out.p;
+      hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, w.p, Ap, m, E, w.partial);
+      hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(64), 0, c->stream, w.partial, scal, E, 1, rtol);
+      hipLaunchKernelGGL(cg_update_xr_kernel, dim3(vblocks), dim3(256), 0, c->stream, w.x, w.r, w.p, Ap, scal, m, E);
+      hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, w.r, w.r, m, E, w.partial);
+      hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(64), 0, c->stream, w.partial, scal, E, 2, rtol);
+      hipLaunchKernelGGL(cg_update_p_kernel, dim3(vblocks), dim3(256), 0, c->stream, w.p, w.r, scal, m, E);
+    }
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess)
+      le = hipMemcpyAsync(state.data(), scal, sizeof(double) * state.size(), hipMemcpyDeviceToHost, c->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(c->stream);
+    if (le != hipSuccess) {
+      c->async_product = false;
+      HIP_TRY(c, le);
+    }
+    for (int e = 0; e < E; ++e) rs[e] = state[e];
+    it = (int)state[(size_t)4 * E + 1];  // iterations that changed the iterate
     rel = worst(rs);
-    ++it;
+    if (state[(size_t)4 * E] != 0.0) break;  // the device met the tolerance inside the burst
   }
+  c->async_product = false;
 
   // true residual ||a - K x|| / ||a|| with one more product
   if ((rc = cg_apply(c, kernel, w.x, m, E))) return rc;
