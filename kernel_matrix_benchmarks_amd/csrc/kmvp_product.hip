@@ -191,6 +191,10 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
   return KMVP_OK;
 }
 
+// Timing marks of a synchronous product; an asynchronous one (solver iteration, possibly inside a
+// stream capture) records nothing.
+inline hipError_t mark(kmvp_ctx* c, int i) { return c->async_product ? hipSuccess : hipEventRecord(c->ev[i], c->stream); }
+
 // Epilogue of the paths with fp64 partials [segment][column][n_pad] in c->part.  Without a
 // communicator one fused launch does it; with one, the segments are summed into c->sums first and
 // finish_product() exchanges them.
@@ -259,7 +263,7 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   int64_t n_pad;
   int segments;
   int64_t seg_len;
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, mark(c, 0));
   if (specialised) {
     LowdTuning tune;
     tune.feed = c->opt_feed >= 0 ? c->opt_feed : DEFAULT_FEED;
@@ -318,7 +322,7 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     a.m_total = c->m_total;
     const int64_t nblocks = tile_blocks * segments;
     if (nblocks > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, mark(c, 0));
     hipError_t le = launch_lowd<real>(kernel, D, E, sig, tune, a, dim3((unsigned)nblocks), c->stream,
                                       &c->last_kernel_name);
     if (le == hipErrorInvalidValue)
@@ -346,13 +350,13 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     segments = (int)((M + seg_len - 1) / seg_len);
     if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
     const real* xg = (const real*)(c->same_points ? c->y_scaled.p : c->x_scaled.p);
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, mark(c, 0));
     HIP_TRY(c, launch_generic<real>(kernel, sig, xg, (const real*)c->y_scaled.p,
                                     sig == SIG_DENSITY ? nullptr : (const real*)c->b_raw.p,
                                     (double*)c->part.p, N, n_pad, M, D, c->E, NE, segments, seg_len,
                                     c->j_offset, c->m_total, c->stream, &c->last_kernel_name));
   }
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, mark(c, 1));
 
   // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
   return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
@@ -385,7 +389,7 @@ int run_product_blocked(kmvp_ctx* c, int kernel, int sig) {
   const int64_t seg_len = round_up((m_pad + segments - 1) / segments, batch);
   segments = (int)((m_pad + seg_len - 1) / seg_len);
 
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, mark(c, 0));
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
                          c->packed_layout != LAYOUT_LOWD || c->packed_T != T;
   if (pts_stale) {
@@ -404,7 +408,7 @@ int run_product_blocked(kmvp_ctx* c, int kernel, int sig) {
 
   const int64_t nblocks = tile_blocks * segments;
   if (nblocks > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, mark(c, 0));
   for (int e0 = 0; e0 < E; e0 += LOWD_MAX_E) {
     const int Ek = std::min(LOWD_MAX_E, E - e0);
     const int sigk = (sig == SIG_NORM && e0 == 0) ? SIG_NORM : SIG_PRODUCT;
@@ -434,7 +438,7 @@ int run_product_blocked(kmvp_ctx* c, int kernel, int sig) {
                        (const double*)c->part.p, (double*)c->sums.p, n_pad, NEk, Ek, segments, e0, E);
     HIP_TRY(c, hipGetLastError());
   }
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, mark(c, 1));
   return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
 }
 
@@ -506,7 +510,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   a.j_offset = c->j_offset;
   a.m_total = c->m_total;
   const dim3 grid((unsigned)(tile_blocks * segments));
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, mark(c, 0));
   hipError_t le;
   switch (kernel) {
     case K_GAUSSIAN: le = launch_fast_gaussian(D, sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
@@ -515,7 +519,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   }
   if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
   HIP_TRY(c, le);
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, mark(c, 1));
 
   // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
   return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
@@ -601,7 +605,7 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   a.j_offset = c->j_offset;
   a.m_total = c->m_total;
   const dim3 grid((unsigned)(tile_blocks * segments));
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, mark(c, 0));
   hipError_t le;
   switch (kernel) {
     case K_GAUSSIAN: le = launch_cfast_gaussian(sig, TT, a, grid, c->stream, &c->last_kernel_name); break;
@@ -610,7 +614,7 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   }
   if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
   HIP_TRY(c, le);
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, mark(c, 1));
 
   // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
   return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
@@ -652,7 +656,7 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
                          c->packed_layout != LAYOUT_MFMA || c->packed_T != TW;
   const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, mark(c, 0));
   if (pts_stale) {
     if ((rc = ensure(c, c->xs, (size_t)n_pad * KD * 2))) return rc;
     hipLaunchKernelGGL(pack_mfma_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream,
@@ -688,7 +692,7 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   a.j_offset = c->j_offset;
   a.m_total = c->m_total;
   const dim3 grid((unsigned)(tile_blocks * segments));
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, mark(c, 0));
   hipError_t le;
   switch (kernel) {
     case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
@@ -696,7 +700,7 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
     default: le = launch_mfma_invdist(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
   }
   HIP_TRY(c, le);
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, mark(c, 1));
 
   const int64_t count = (int64_t)NE * n_pad;
   if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
@@ -740,9 +744,9 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     const int64_t NE = sig0 == SIG_NORM ? E + 1 : E;
     int rc = ensure(c, c->sums, (size_t)NE * c->N * sizeof(double));
     if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, mark(c, 0));
     HIP_TRY(c, hipMemsetAsync(c->sums.p, 0, (size_t)NE * c->N * sizeof(double), c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, mark(c, 1));
     c->last_kernel_name = "none";
     if (c->density && normalise) {  // every rank takes the all-ones shortcut below: no exchange
     } else {

@@ -2,6 +2,8 @@
 // gradients (SPD Gaussian / exp(-r) matrices) and MINRES (symmetric indefinite
 // inverse-distance matrix).  The reference solves densely with lstsq (bruteforce.py:205-207);
 // parity is judged on the residual.
+#include <cstdlib>
+
 #include "kmvp_ctx.hpp"
 
 namespace kmvp {
@@ -80,6 +82,7 @@ __global__ void cg_widen_kernel(const real* __restrict__ in, double* __restrict_
 }
 
 constexpr int CG_CHECK = 8;  // iterations between two looks at the residual on the host
+constexpr int CG_GRAPH_AFTER = 64;  // bursts (512 iterations) before the burst is captured into a hipGraph
 
 // One block.  mode 1: pAp[e] = sum of the partials -> alpha[e] = rs_old[e] / pAp[e];
 // mode 2: rs_new[e] = sum -> beta[e] = rs_new[e] / rs_old[e], rs_old[e] = rs_new[e], iteration count + 1,
@@ -260,13 +263,14 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
   int it = 0;
   double rel = worst(rs);
   c->async_product = true;
-  while (it < maxit && rel > rtol) {
-    const int burst = std::min(CG_CHECK, maxit - it);
+  // one burst = CG_CHECK iterations of ~10 launches each.  A solve that is still running after
+  // CG_GRAPH_AFTER bursts replays the burst as a hipGraph from then on (instantiating the 80-node
+  // graph costs ~70 ms on this stack, so short solves never pay for it; single GPU only: with a
+  // communicator the all-reduce stays out of graphs).  KMVP_NO_GRAPH=1 disables it.
+  auto run_burst = [&](int burst) -> int {
     for (int k = 0; k < burst; ++k) {
-      if ((rc = cg_apply(c, kernel, w.p, m, E))) {
-        c->async_product = false;
-        return rc;
-      }
+      int rcb = cg_apply(c, kernel, w.p, m, E);
+      if (rcb) return rcb;
       const double* Ap = (const double*)c->out.p;
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, w.p, Ap, m, E, w.partial);
       hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(64), 0, c->stream, w.partial, scal, E, 1, rtol);
@@ -274,6 +278,48 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, w.r, w.r, m, E, w.partial);
       hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(64), 0, c->stream, w.partial, scal, E, 2, rtol);
       hipLaunchKernelGGL(cg_update_p_kernel, dim3(vblocks), dim3(256), 0, c->stream, w.p, w.r, scal, m, E);
+    }
+    return KMVP_OK;
+  };
+  hipGraphExec_t gexec = nullptr;
+  bool try_graph = c->comm == nullptr && getenv("KMVP_NO_GRAPH") == nullptr;
+  int full_bursts = 0;
+  while (it < maxit && rel > rtol) {
+    const int burst = std::min(CG_CHECK, maxit - it);
+    if (gexec && burst == CG_CHECK) {
+      if (hipGraphLaunch(gexec, c->stream) != hipSuccess) rc = fail(c, KMVP_E_DEVICE, "hipGraphLaunch failed");
+    } else if (try_graph && full_bursts >= CG_GRAPH_AFTER && burst == CG_CHECK) {
+      // every buffer exists and every layout decision has been taken by the first burst: capture
+      if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        rc = run_burst(burst);
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+        if (rc == KMVP_OK && ee == hipSuccess && graph &&
+            hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
+          gexec = nullptr;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (rc == KMVP_OK) {
+          if (gexec) {
+            if (hipGraphLaunch(gexec, c->stream) != hipSuccess) rc = fail(c, KMVP_E_DEVICE, "hipGraphLaunch failed");
+          } else {
+            (void)hipGetLastError();  // capture refused: nothing ran, go on launch by launch
+            try_graph = false;
+            rc = run_burst(burst);
+          }
+        }
+      } else {
+        (void)hipGetLastError();
+        try_graph = false;
+        rc = run_burst(burst);
+      }
+    } else {
+      rc = run_burst(burst);
+    }
+    if (burst == CG_CHECK) ++full_bursts;
+    if (rc) {
+      c->async_product = false;
+      if (gexec) (void)hipGraphExecDestroy(gexec);
+      return rc;
     }
     hipError_t le = hipGetLastError();
     if (le == hipSuccess)
@@ -288,6 +334,7 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
     rel = worst(rs);
     if (state[(size_t)4 * E] != 0.0) break;  // the device met the tolerance inside the burst
   }
+  if (gexec) (void)hipGraphExecDestroy(gexec);
   c->async_product = false;
 
   // true residual ||a - K x|| / ||a|| with one more product
