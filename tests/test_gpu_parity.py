@@ -582,6 +582,32 @@ def test_cg_solver_config5_shape_small():
     assert np.linalg.norm(Kb - a[rows]) / np.linalg.norm(a[rows]) <= 5e-6
 
 
+def test_long_cg_graph_replay_equals_plain_launches():
+    """After 512 iterations the CG burst is replayed as a hipGraph: same iterates as launch by launch."""
+    import os
+
+    n = 1200
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    y = y * 4.0
+    a = kmvp_oracle.product(kernel="gaussian", source_points=y, source_signal=b)
+    outs = []
+    for no_graph in (False, True):
+        if no_graph:
+            os.environ["KMVP_NO_GRAPH"] = "1"
+        else:
+            os.environ.pop("KMVP_NO_GRAPH", None)
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_points(y, None, _lib.KMVP_F64)
+            sol, iters, resid, ok = ctx.cg_solve("gaussian", a, 1e-13, 1000)  # unreachable tolerance: runs to maxit
+        finally:
+            ctx.close()
+            os.environ.pop("KMVP_NO_GRAPH", None)
+        assert iters == 1000
+        outs.append(sol)
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_solver_in_the_sharded_shape_on_one_gpu():
     """The multi-GPU solver hands every rank ALL points as targets and a slice as
     sources, Krylov vectors replicated.  With one rank the slice is everything: same operator,
