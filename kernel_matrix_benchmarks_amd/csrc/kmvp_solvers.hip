@@ -395,6 +395,110 @@ __global__ void vec_lin3_inline_kernel(double* __restrict__ out, const double* _
   out[q] = v;
 }
 
+// ---- MINRES on the device.  State per column e (doubles): see MS_* below; five coefficient
+// triples [3E] feed vec_lin3_dev_kernel.  Same scalar arithmetic, in the same order, as the
+// textbook recurrence on the host would do.
+enum : int { MS_BETA1 = 0, MS_BETA, MS_OLDB, MS_ALFA, MS_DBAR, MS_EPSLN, MS_CS, MS_SN, MS_PHIBAR, MS_DONE, MS_FIELDS };
+// layout: state[MS_FIELDS][E] | T0..T4 [5][3E] | stop | iterations
+__host__ __device__ inline size_t ms_triple(int E, int t) { return (size_t)MS_FIELDS * E + (size_t)t * 3 * E; }
+__host__ __device__ inline size_t ms_stop(int E) { return (size_t)MS_FIELDS * E + 15 * (size_t)E; }
+
+// out = c0 a + c1 b + c2 c with the coefficient triple in device memory; nothing once stopped
+__global__ void vec_lin3_dev_kernel(double* __restrict__ out, const double* __restrict__ a,
+                                    const double* __restrict__ b, const double* __restrict__ c,
+                                    const double* __restrict__ coef, const double* __restrict__ stop, int64_t m,
+                                    int E) {
+  if (*stop != 0.0) return;
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m * E) return;
+  const int e = (int)(q % E);
+  double v = coef[e] * a[q];
+  if (b) v += coef[E + e] * b[q];
+  if (c) v += coef[2 * E + e] * c[q];
+  out[q] = v;
+}
+
+__global__ void vec_copy_dev_kernel(double* __restrict__ out, const double* __restrict__ in,
+                                    const double* __restrict__ stop, int64_t count) {
+  if (*stop != 0.0) return;
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < count) out[q] = in[q];
+}
+
+// mode 1 (after v.y): alfa, T2 = (1, -alfa/beta, 0).
+// mode 2 (after r2.r2): the Givens step, T3 (w update), T4 (x update), the done flags, the stopping
+// test max_e phibar/beta1 <= rtol, and the next iteration's T0 = (1/beta, 0, 0), T1 = (1, -beta/oldb, 0).
+__global__ void minres_scalars_kernel(const double* __restrict__ partial, double* __restrict__ st, int E, int mode,
+                                      double rtol) {
+#pragma clang fp contract(off)  // the rotation exactly as written (no fused multiply-adds)
+  double* stop = st + ms_stop(E);
+  if (*stop != 0.0) return;
+  __shared__ int not_met;
+  if (threadIdx.x == 0) not_met = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    double dot = 0.0;
+    for (int b = 0; b < CG_BLOCKS; ++b) dot += partial[(int64_t)b * E + e];
+    auto S = [&](int f) -> double& { return st[(size_t)f * E + e]; };
+    double* T0 = st + ms_triple(E, 0);
+    double* T1 = st + ms_triple(E, 1);
+    double* T2 = st + ms_triple(E, 2);
+    double* T3 = st + ms_triple(E, 3);
+    double* T4 = st + ms_triple(E, 4);
+    if (mode == 1) {
+      S(MS_ALFA) = dot;
+      T2[e] = 1.0;
+      T2[E + e] = S(MS_BETA) > 0.0 ? -dot / S(MS_BETA) : 0.0;
+      T2[2 * E + e] = 0.0;
+    } else {
+      const double alfa = S(MS_ALFA), cs0 = S(MS_CS), sn0 = S(MS_SN), dbar0 = S(MS_DBAR);
+      const double oldb = S(MS_BETA);
+      const double beta = sqrt(fmax(dot, 0.0));
+      const double oldeps = S(MS_EPSLN);
+      const double delta = cs0 * dbar0 + sn0 * alfa;
+      const double gbar = sn0 * dbar0 - cs0 * alfa;
+      const double epsln = sn0 * beta;
+      const double dbar = -cs0 * beta;
+      const double gamma = fmax(sqrt(gbar * gbar + beta * beta), 1e-300);
+      const double cs = gbar / gamma, sn = beta / gamma;
+      const double phi = cs * S(MS_PHIBAR);
+      const double phibar = sn * S(MS_PHIBAR);
+      const bool done0 = S(MS_DONE) != 0.0;
+      const double dn = done0 ? 0.0 : 1.0 / gamma;
+      T3[e] = dn;
+      T3[E + e] = -oldeps * dn;
+      T3[2 * E + e] = -delta * dn;
+      T4[e] = 1.0;
+      T4[E + e] = done0 ? 0.0 : phi;
+      T4[2 * E + e] = 0.0;
+      S(MS_OLDB) = oldb;
+      S(MS_BETA) = beta;
+      S(MS_EPSLN) = epsln;
+      S(MS_DBAR) = dbar;
+      S(MS_CS) = cs;
+      S(MS_SN) = sn;
+      S(MS_PHIBAR) = phibar;
+      const bool done1 = done0 || phibar <= rtol * S(MS_BETA1) || beta == 0.0;
+      S(MS_DONE) = done1 ? 1.0 : 0.0;
+      // next iteration
+      T0[e] = (!done1 && beta > 0.0) ? 1.0 / beta : 0.0;
+      T0[E + e] = 0.0;
+      T0[2 * E + e] = 0.0;
+      T1[e] = 1.0;
+      T1[E + e] = oldb > 0.0 ? -beta / oldb : 0.0;
+      T1[2 * E + e] = 0.0;
+      if (S(MS_BETA1) > 0.0 && phibar / S(MS_BETA1) > rtol) atomicOr(&not_met, 1);
+    }
+  }
+  if (mode == 2) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      stop[1] += 1.0;
+      if (!not_met) *stop = 1.0;
+    }
+  }
+}
+
 int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, int maxit,
                  double* out_b, int* iters, double* resid) {
   if (!c) return KMVP_E_INVALID;
@@ -405,7 +509,7 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
   const int64_t m = c->N;  // length of the Krylov vectors: all points
   const size_t n = (size_t)m * E;
   const size_t vec = n * sizeof(double);
-  int rc = ensure(c, c->scratch, 8 * vec + sizeof(double) * ((CG_BLOCKS + 3) * (size_t)E));
+  int rc = ensure(c, c->scratch, 8 * vec + sizeof(double) * ((CG_BLOCKS + 3) * (size_t)E + ms_stop(E) + 2));
   if (rc) return rc;
   double* base = (double*)c->scratch.p;
   double *x = base, *r1 = base + n, *r2 = base + 2 * n, *y = base + 3 * n, *v = base + 4 * n;
@@ -451,90 +555,78 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if ((rc = cg_dots(c, y, y, m, E, wk, hp, dots))) return rc;
 
-  std::vector<double> beta1(E), beta(E), oldb(E, 0.0), dbar(E, 0.0), epsln(E, 0.0), phibar(E), cs(E, -1.0),
-      sn(E, 0.0), alfa(E), oldeps(E), delta(E), gbar(E), gamma(E), phi(E);
-  std::vector<char> done(E, 0);
+  // ---- device-resident recurrence (see minres_scalars_kernel); the host rotates buffer pointers and
+  // looks at the residual every CG_CHECK iterations
+  std::vector<double> beta1(E);
+  double* st = wk.coef + 3 * (size_t)E;
+  const size_t st_len = ms_stop(E) + 2;
+  std::vector<double> state(st_len, 0.0);
   for (int e = 0; e < E; ++e) {
     beta1[e] = std::sqrt(dots[e]);
-    beta[e] = beta1[e];
-    phibar[e] = beta1[e];
-    if (!(beta1[e] > 0.0)) done[e] = 1;  // zero right-hand side: x = 0
+    state[(size_t)MS_BETA1 * E + e] = beta1[e];
+    state[(size_t)MS_BETA * E + e] = beta1[e];
+    state[(size_t)MS_CS * E + e] = -1.0;
+    state[(size_t)MS_PHIBAR * E + e] = beta1[e];
+    const bool zero_rhs = !(beta1[e] > 0.0);  // x = 0
+    state[(size_t)MS_DONE * E + e] = zero_rhs ? 1.0 : 0.0;
+    state[ms_triple(E, 0) + e] = (!zero_rhs) ? 1.0 / beta1[e] : 0.0;  // T0 = (1/beta, 0, 0)
+    state[ms_triple(E, 1) + e] = 1.0;                                   // T1 = (1, 0, 0): no r1 term in iteration 1
   }
+  HIP_TRY(c, hipMemcpyAsync(st, state.data(), sizeof(double) * st_len, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double* stop = st + ms_stop(E);
+  const unsigned vb = blocks_for((int64_t)n);
   auto worst = [&]() {
     double wv = 0.0;
     for (int e = 0; e < E; ++e)
-      if (beta1[e] > 0.0) wv = std::max(wv, phibar[e] / beta1[e]);
+      if (beta1[e] > 0.0) wv = std::max(wv, state[(size_t)MS_PHIBAR * E + e] / beta1[e]);
     return wv;
+  };
+  auto dlin3 = [&](double* out, const double* pa, const double* pb, const double* pc, int triple) {
+    hipLaunchKernelGGL(vec_lin3_dev_kernel, dim3(vb), dim3(256), 0, c->stream, out, pa, pb, pc,
+                       st + ms_triple(E, triple), stop, m, E);
   };
 
   int it = 0;
   double rel = worst();
+  c->async_product = true;
   while (it < maxit && rel > rtol) {
-    ++it;
-    // v = y / beta
-    for (int e = 0; e < E; ++e) coef[e] = (!done[e] && beta[e] > 0.0) ? 1.0 / beta[e] : 0.0;
-    if ((rc = lin3(v, y, nullptr, nullptr))) return rc;
-    // y = K v - (beta / oldb) r1
-    if ((rc = cg_apply(c, kernel, v, m, E))) return rc;
-    for (int e = 0; e < E; ++e) {
-      coef[e] = 1.0;
-      coef[E + e] = (it >= 2 && oldb[e] > 0.0) ? -beta[e] / oldb[e] : 0.0;
+    const int burst = std::min(CG_CHECK, maxit - it);
+    for (int k = 0; k < burst; ++k) {
+      dlin3(v, y, nullptr, nullptr, 0);  // v = y / beta
+      if ((rc = cg_apply(c, kernel, v, m, E))) {
+        c->async_product = false;
+        return rc;
+      }
+      dlin3(y, (const double*)c->out.p, r1, nullptr, 1);  // y = K v - (beta / oldb) r1
+      hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, v, y, m, E, wk.partial);
+      hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(64), 0, c->stream, wk.partial, st, E, 1, rtol);
+      dlin3(r1, y, r2, nullptr, 2);  // y - (alfa / beta) r2, written into the old r1 buffer
+      std::swap(r1, r2);             // r1 <- r2, r2 <- the new vector
+      hipLaunchKernelGGL(vec_copy_dev_kernel, dim3(vb), dim3(256), 0, c->stream, y, r2, stop, (int64_t)n);
+      hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, r2, r2, m, E, wk.partial);
+      hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(64), 0, c->stream, wk.partial, st, E, 2, rtol);
+      {  // w_new = (v - oldeps w1 - delta w2) / gamma with w1 <- w2, w2 <- w
+        double* t = w1;
+        w1 = w2;
+        w2 = w;
+        w = t;
+      }
+      dlin3(w, v, w1, w2, 3);
+      dlin3(x, x, w, nullptr, 4);  // x = x + phi w
     }
-    if ((rc = lin3(y, (const double*)c->out.p, r1, nullptr))) return rc;
-    if ((rc = cg_dots(c, v, y, m, E, wk, hp, dots))) return rc;
-    for (int e = 0; e < E; ++e) alfa[e] = dots[e];
-    // y = y - (alfa / beta) r2 ; then r1 <- r2, r2 <- y (buffer rotation)
-    for (int e = 0; e < E; ++e) {
-      coef[e] = 1.0;
-      coef[E + e] = beta[e] > 0.0 ? -alfa[e] / beta[e] : 0.0;
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = hipMemcpyAsync(state.data(), st, sizeof(double) * st_len, hipMemcpyDeviceToHost, c->stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(c->stream);
+    if (le != hipSuccess) {
+      c->async_product = false;
+      HIP_TRY(c, le);
     }
-    if ((rc = lin3(r1, y, r2, nullptr))) return rc;  // written into the old r1 buffer
-    {
-      double* newy = r1;
-      r1 = r2;
-      r2 = newy;
-      // y must alias r2's content for the next iteration's "v = y / beta": keep y as its own buffer
-      HIP_TRY(c, hipMemcpyAsync(y, r2, vec, hipMemcpyDeviceToDevice, c->stream));
-    }
-    if ((rc = cg_dots(c, r2, r2, m, E, wk, hp, dots))) return rc;
-    for (int e = 0; e < E; ++e) {
-      oldb[e] = beta[e];
-      beta[e] = std::sqrt(std::max(dots[e], 0.0));
-      oldeps[e] = epsln[e];
-      delta[e] = cs[e] * dbar[e] + sn[e] * alfa[e];
-      gbar[e] = sn[e] * dbar[e] - cs[e] * alfa[e];
-      epsln[e] = sn[e] * beta[e];
-      dbar[e] = -cs[e] * beta[e];
-      gamma[e] = std::max(std::sqrt(gbar[e] * gbar[e] + beta[e] * beta[e]), 1e-300);
-      cs[e] = gbar[e] / gamma[e];
-      sn[e] = beta[e] / gamma[e];
-      phi[e] = cs[e] * phibar[e];
-      phibar[e] = sn[e] * phibar[e];
-    }
-    // w_new = (v - oldeps w1 - delta w2) / gamma with w1 <- w2, w2 <- w
-    {
-      double* t = w1;
-      w1 = w2;
-      w2 = w;
-      w = t;
-    }
-    for (int e = 0; e < E; ++e) {
-      const double dn = done[e] ? 0.0 : 1.0 / gamma[e];
-      coef[e] = dn;
-      coef[E + e] = -oldeps[e] * dn;
-      coef[2 * E + e] = -delta[e] * dn;
-    }
-    if ((rc = lin3(w, v, w1, w2))) return rc;
-    // x = x + phi w
-    for (int e = 0; e < E; ++e) {
-      coef[e] = 1.0;
-      coef[E + e] = done[e] ? 0.0 : phi[e];
-    }
-    if ((rc = lin3(x, x, w, nullptr))) return rc;
-    for (int e = 0; e < E; ++e)
-      if (!done[e] && (phibar[e] <= rtol * beta1[e] || beta[e] == 0.0)) done[e] = 1;
+    it = (int)state[ms_stop(E) + 1];
     rel = worst();
+    if (state[ms_stop(E)] != 0.0) break;
   }
+  c->async_product = false;
 
   // true residual ||a - K x|| / ||a||
   if ((rc = cg_apply(c, kernel, x, m, E))) return rc;

@@ -690,7 +690,9 @@ def test_runner_solver_dataset_on_gpu(tmp_path):
         for fn, attrs, result in stored:
             assert attrs["algo"] == "mi355x-solver" and result.shape == (400, 1)
             assert attrs["cg_converged"], attrs
-            assert attrs["cg_relative_residual"] <= (1e-6 if "float64" in attrs["name"] else 1e-4)
+            # the solvers stop on the recurrence residual; the TRUE residual they report may exceed rtol
+            # by rounding (accepted up to 1.5 rtol, kmvp_solvers.hip)
+            assert attrs["cg_relative_residual"] <= (1.5e-6 if "float64" in attrs["name"] else 1.5e-4)
 
 
 def test_rccl_binds_to_the_hip_runtime_in_use():
