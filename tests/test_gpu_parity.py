@@ -219,6 +219,47 @@ def test_random_shapes_flags_and_precisions():
                                           rel_err(got, want))
 
 
+def test_random_options_never_break_a_product():
+    """Seeded sweep over the tuning options (segments, tiles per wave, forced squared-distance forms,
+    feeds): options that do not apply fall back silently, every combination returns the right sums
+    (the forced global-centre form is only held to its own accuracy class for the Gaussian)."""
+    rs = np.random.RandomState(777)
+    for case_no in range(60):
+        kernel = golden_cases.KERNELS[case_no % 3]
+        D = int(rs.choice([1, 3, 3, 4, 6, 8, 12]))
+        M = int(rs.choice([40, 257, 1000, 3000]))
+        same = bool(rs.rand() < 0.6)
+        N = M if same else int(rs.choice([33, 300, 2000]))
+        norm = bool(rs.rand() < 0.3)
+        y = rs.rand(M, D)
+        x = None if same else rs.rand(N, D)
+        b = rs.randn(M, 1)
+        opts = {}
+        if rs.rand() < 0.7:
+            opts["fast_sqdists"] = [None, False, True, "centred"][int(rs.randint(4))]
+        if rs.rand() < 0.5:
+            opts["segments"] = int(rs.choice([1, 2, 3, 8, 17]))
+        if rs.rand() < 0.5:
+            opts["fast_tiles"] = int(rs.choice([1, 2, 4]))
+        if rs.rand() < 0.3:
+            opts["targets_per_lane"] = int(rs.choice([1, 2]))
+        if rs.rand() < 0.3:
+            opts["feed"] = int(rs.choice([0, 1]))
+        if opts.get("targets_per_lane") == 1 and opts.get("feed") == 0 and D != 3:
+            opts.pop("feed")  # (T = 1, scalar feed) is only instantiated for the headline shape
+        if opts.get("targets_per_lane") == 2 and opts.get("feed") == 1 and D != 3:
+            opts.pop("feed")
+        y32 = y.astype(np.float32).astype(np.float64)
+        x32 = None if x is None else x.astype(np.float32).astype(np.float64)
+        b32 = b.astype(np.float32).astype(np.float64)
+        want = kmvp_oracle.product(kernel=kernel, source_points=y32, target_points=x32, source_signal=b32,
+                                   normalize_rows=norm)
+        got, extra = run_plugin(dict(kernel=kernel, D=D, normalize_rows=norm), y, x, b, "float32", **opts)
+        forced_global = opts.get("fast_sqdists") is True and extra["device_kernel"] == "fast_kernel"
+        tol = 2e-5 if (not forced_global or kernel == "gaussian") else 5e-2
+        assert rel_err(got, want) <= tol, (case_no, kernel, D, N, M, same, norm, opts, extra["device_kernel"], rel_err(got, want))
+
+
 def test_matrix_core_kernels_reproducible_and_tile_count_independent():
     """LDS-DMA staged kernels must not depend on timing: bitwise identical results run to run at a
     size where every CU is busy, and the same sums (to float32 rounding) whatever the number of
