@@ -81,6 +81,20 @@ __global__ void cg_widen_kernel(const real* __restrict__ in, double* __restrict_
   if (q < n) out[q] = (double)in[q];
 }
 
+// Sum of the CG_BLOCKS partials of column e by the whole block (fixed tree order: deterministic).
+// A single thread walking the 256 partials took ~9 us per call; this takes ~2.
+__device__ __forceinline__ double block_sum_partials(const double* __restrict__ partial, int E, int e, double* red) {
+  red[threadIdx.x] = threadIdx.x < CG_BLOCKS ? partial[(int64_t)threadIdx.x * E + e] : 0.0;
+  __syncthreads();
+  for (int s2 = CG_BLOCKS / 2; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    __syncthreads();
+  }
+  const double v = red[0];
+  __syncthreads();
+  return v;
+}
+
 constexpr int CG_CHECK = 8;  // iterations between two looks at the residual on the host
 constexpr int CG_GRAPH_AFTER = 64;  // bursts (512 iterations) before the burst is captured into a hipGraph
 
@@ -92,16 +106,16 @@ constexpr int CG_GRAPH_AFTER = 64;  // bursts (512 iterations) before the burst 
 // monotonically: at config 5 it meets 1e-6 at iteration 132 and not again before 240).
 // scal = [rs_old | alpha | beta | |a|^2] x E, then stop, iterations.  Partials are added in block
 // order, as the host would.
-__global__ void cg_scalars_kernel(const double* __restrict__ partial, double* __restrict__ scal, int E, int mode,
-                                  double rtol) {
+__global__ void __launch_bounds__(CG_BLOCKS) cg_scalars_kernel(const double* __restrict__ partial,
+                                                              double* __restrict__ scal, int E, int mode,
+                                                              double rtol) {
+  __shared__ double red[CG_BLOCKS];
   double* stop = scal + 4 * E;
-  if (*stop != 0.0) return;
-  __shared__ int not_met;
-  if (threadIdx.x == 0) not_met = 0;
-  __syncthreads();
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    double v = 0.0;
-    for (int b = 0; b < CG_BLOCKS; ++b) v += partial[(int64_t)b * E + e];
+  if (*stop != 0.0) return;  // uniform: every thread reads the same word
+  bool not_met = false;
+  for (int e = 0; e < E; ++e) {
+    const double v = block_sum_partials(partial, E, e, red);
+    if (threadIdx.x != 0) continue;
     const double rs_old = scal[e];
     if (mode == 1) {
       scal[E + e] = (v != 0.0 && rs_old > 0.0) ? rs_old / v : 0.0;
@@ -109,15 +123,12 @@ __global__ void cg_scalars_kernel(const double* __restrict__ partial, double* __
       scal[2 * E + e] = rs_old > 0.0 ? v / rs_old : 0.0;
       scal[e] = v;
       const double a2 = scal[3 * E + e];
-      if (a2 > 0.0 && sqrt(v / a2) > rtol) atomicOr(&not_met, 1);
+      if (a2 > 0.0 && sqrt(v / a2) > rtol) not_met = true;
     }
   }
-  if (mode == 2) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      scal[4 * E + 1] += 1.0;
-      if (!not_met) *stop = 1.0;
-    }
+  if (mode == 2 && threadIdx.x == 0) {
+    scal[4 * E + 1] += 1.0;
+    if (!not_met) *stop = 1.0;
   }
 }
 
@@ -273,10 +284,10 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
       if (rcb) return rcb;
       const double* Ap = (const double*)c->out.p;
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, w.p, Ap, m, E, w.partial);
-      hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(64), 0, c->stream, w.partial, scal, E, 1, rtol);
+      hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(CG_BLOCKS), 0, c->stream, w.partial, scal, E, 1, rtol);
       hipLaunchKernelGGL(cg_update_xr_kernel, dim3(vblocks), dim3(256), 0, c->stream, w.x, w.r, w.p, Ap, scal, m, E);
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, w.r, w.r, m, E, w.partial);
-      hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(64), 0, c->stream, w.partial, scal, E, 2, rtol);
+      hipLaunchKernelGGL(cg_scalars_kernel, dim3(1), dim3(CG_BLOCKS), 0, c->stream, w.partial, scal, E, 2, rtol);
       hipLaunchKernelGGL(cg_update_p_kernel, dim3(vblocks), dim3(256), 0, c->stream, w.p, w.r, scal, m, E);
     }
     return KMVP_OK;
@@ -428,23 +439,23 @@ __global__ void vec_copy_dev_kernel(double* __restrict__ out, const double* __re
 // mode 1 (after v.y): alfa, T2 = (1, -alfa/beta, 0).
 // mode 2 (after r2.r2): the Givens step, T3 (w update), T4 (x update), the done flags, the stopping
 // test max_e phibar/beta1 <= rtol, and the next iteration's T0 = (1/beta, 0, 0), T1 = (1, -beta/oldb, 0).
-__global__ void minres_scalars_kernel(const double* __restrict__ partial, double* __restrict__ st, int E, int mode,
-                                      double rtol) {
+__global__ void __launch_bounds__(CG_BLOCKS) minres_scalars_kernel(const double* __restrict__ partial,
+                                                                  double* __restrict__ st, int E, int mode,
+                                                                  double rtol) {
 #pragma clang fp contract(off)  // the rotation exactly as written (no fused multiply-adds)
+  __shared__ double red[CG_BLOCKS];
   double* stop = st + ms_stop(E);
   if (*stop != 0.0) return;
-  __shared__ int not_met;
-  if (threadIdx.x == 0) not_met = 0;
-  __syncthreads();
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    double dot = 0.0;
-    for (int b = 0; b < CG_BLOCKS; ++b) dot += partial[(int64_t)b * E + e];
+  bool not_met = false;
+  double* T0 = st + ms_triple(E, 0);
+  double* T1 = st + ms_triple(E, 1);
+  double* T2 = st + ms_triple(E, 2);
+  double* T3 = st + ms_triple(E, 3);
+  double* T4 = st + ms_triple(E, 4);
+  for (int e = 0; e < E; ++e) {
+    const double dot = block_sum_partials(partial, E, e, red);
+    if (threadIdx.x != 0) continue;
     auto S = [&](int f) -> double& { return st[(size_t)f * E + e]; };
-    double* T0 = st + ms_triple(E, 0);
-    double* T1 = st + ms_triple(E, 1);
-    double* T2 = st + ms_triple(E, 2);
-    double* T3 = st + ms_triple(E, 3);
-    double* T4 = st + ms_triple(E, 4);
     if (mode == 1) {
       S(MS_ALFA) = dot;
       T2[e] = 1.0;
@@ -487,15 +498,12 @@ __global__ void minres_scalars_kernel(const double* __restrict__ partial, double
       T1[e] = 1.0;
       T1[E + e] = oldb > 0.0 ? -beta / oldb : 0.0;
       T1[2 * E + e] = 0.0;
-      if (S(MS_BETA1) > 0.0 && phibar / S(MS_BETA1) > rtol) atomicOr(&not_met, 1);
+      if (S(MS_BETA1) > 0.0 && phibar / S(MS_BETA1) > rtol) not_met = true;
     }
   }
-  if (mode == 2) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      stop[1] += 1.0;
-      if (!not_met) *stop = 1.0;
-    }
+  if (mode == 2 && threadIdx.x == 0) {
+    stop[1] += 1.0;
+    if (!not_met) *stop = 1.0;
   }
 }
 
@@ -600,12 +608,12 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
       }
       dlin3(y, (const double*)c->out.p, r1, nullptr, 1);  // y = K v - (beta / oldb) r1
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, v, y, m, E, wk.partial);
-      hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(64), 0, c->stream, wk.partial, st, E, 1, rtol);
+      hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(CG_BLOCKS), 0, c->stream, wk.partial, st, E, 1, rtol);
       dlin3(r1, y, r2, nullptr, 2);  // y - (alfa / beta) r2, written into the old r1 buffer
       std::swap(r1, r2);             // r1 <- r2, r2 <- the new vector
       hipLaunchKernelGGL(vec_copy_dev_kernel, dim3(vb), dim3(256), 0, c->stream, y, r2, stop, (int64_t)n);
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, r2, r2, m, E, wk.partial);
-      hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(64), 0, c->stream, wk.partial, st, E, 2, rtol);
+      hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(CG_BLOCKS), 0, c->stream, wk.partial, st, E, 2, rtol);
       {  // w_new = (v - oldeps w1 - delta w2) / gamma with w1 <- w2, w2 <- w
         double* t = w1;
         w1 = w2;
