@@ -2,11 +2,12 @@
 // included by kmvp_product.hip only).  Layouts are documented in kmvp_cfast.hpp.
 #pragma once
 #include "kmvp_cfast.hpp"
+#include "kmvp_fast_pack.hpp"  // aux layout (FAST_AUX_*)
 
 namespace kmvp {
 
 // Morton key of every source from its position inside the clouds' bounding box
-// (centre[0..D) and half-widths centre[9..9+D), written by fast_center_kernel);
+// (centre[0..D) and half-widths centre[FAST_AUX_HALF..), written by fast_center_kernel);
 // floor(30 / D) bits per dimension.  Pad entries (j >= m) sort last.
 __global__ void cfast_morton_kernel(const float* __restrict__ y, const float* __restrict__ centre,
                                     unsigned* __restrict__ keys, int* __restrict__ vals, int64_t m,
@@ -22,7 +23,7 @@ __global__ void cfast_morton_kernel(const float* __restrict__ y, const float* __
   unsigned key = 0;
   unsigned q[4] = {0, 0, 0, 0};
   for (int d = 0; d < D; ++d) {
-    const float half = centre[9 + d];
+    const float half = centre[FAST_AUX_HALF + d];
     float t = half > 0.f ? (y[j * D + d] - centre[d]) / (2.f * half) + 0.5f : 0.f;  // [0, 1]
     t = fminf(fmaxf(t, 0.f), 0.999999f);
     q[d] = (unsigned)(t * (float)(1u << bits));

@@ -5,23 +5,33 @@
 
 namespace kmvp {
 
-// centre[d] = midpoint of the bounding box of both clouds, centre[8] = squared half-diagonal
-// of that box, centre[9 + d] = half-width along d (one workgroup; runs once per kmvp_set_points).  Subtracting the centre before
-// the |x|^2 + |y|^2 - 2x.y expansion keeps the cancellation error of the fast form as small
-// as the data allow; the half-diagonal bounds |x'|^2, |y'|^2 and drives the "auto" choice.
-__global__ void fast_center_kernel(const float* __restrict__ y, int64_t m, const float* __restrict__ x,
-                                   int64_t n, int D, float* __restrict__ centre) {
-  __shared__ float lo[1024], hi[1024];
-  float radius2 = 0.f;
+// Bounding box of both clouds in two launches (once per kmvp_set_points): FAST_BBOX_BLOCKS blocks
+// reduce strided subsets per dimension, one block finishes.  aux layout (floats):
+//   [0, D) centre = midpoint of the box, [FAST_AUX_RADIUS2] squared half-diagonal,
+//   [FAST_AUX_HALF, FAST_AUX_HALF + D) half-widths.
+// Subtracting the centre before the |x|^2 + |y|^2 - 2x.y expansion keeps the cancellation error of
+// the fast form as small as the data allow; the half-diagonal bounds |x'|^2, |y'|^2 and drives the
+// "auto" choice; the Morton keys of kmvp_cfast_pack.hpp are taken relative to the box.
+constexpr int FAST_AUX_RADIUS2 = 64;
+constexpr int FAST_AUX_HALF = 65;
+constexpr int FAST_AUX_FLOATS = 160;
+constexpr int FAST_BBOX_BLOCKS = 256;
+
+__global__ void __launch_bounds__(256) fast_bbox_partial_kernel(const float* __restrict__ y, int64_t m,
+                                                               const float* __restrict__ x, int64_t n, int D,
+                                                               float* __restrict__ part /* [blocks][D][2] */) {
+  __shared__ float lo[256], hi[256];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int d = 0; d < D; ++d) {
     float vmin = INFINITY, vmax = -INFINITY;
-    for (int64_t i = threadIdx.x; i < m; i += blockDim.x) {
+    for (int64_t i = first; i < m; i += stride) {
       const float v = y[i * D + d];
       vmin = fminf(vmin, v);
       vmax = fmaxf(vmax, v);
     }
     if (x != nullptr)
-      for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      for (int64_t i = first; i < n; i += stride) {
         const float v = x[i * D + d];
         vmin = fminf(vmin, v);
         vmax = fmaxf(vmax, v);
@@ -37,16 +47,39 @@ __global__ void fast_center_kernel(const float* __restrict__ y, int64_t m, const
       __syncthreads();
     }
     if (threadIdx.x == 0) {
+      part[((int64_t)blockIdx.x * D + d) * 2 + 0] = lo[0];
+      part[((int64_t)blockIdx.x * D + d) * 2 + 1] = hi[0];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(FAST_BBOX_BLOCKS) fast_center_kernel(const float* __restrict__ part, int D,
+                                                                      float* __restrict__ centre) {
+  __shared__ float lo[FAST_BBOX_BLOCKS], hi[FAST_BBOX_BLOCKS];
+  float radius2 = 0.f;
+  for (int d = 0; d < D; ++d) {
+    lo[threadIdx.x] = part[((int64_t)threadIdx.x * D + d) * 2 + 0];
+    hi[threadIdx.x] = part[((int64_t)threadIdx.x * D + d) * 2 + 1];
+    __syncthreads();
+    for (int s = FAST_BBOX_BLOCKS / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        lo[threadIdx.x] = fminf(lo[threadIdx.x], lo[threadIdx.x + s]);
+        hi[threadIdx.x] = fmaxf(hi[threadIdx.x], hi[threadIdx.x + s]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
       const float c = 0.5f * (lo[0] + hi[0]);
       const bool ok = (c == c && fabsf(c) != INFINITY);
       centre[d] = ok ? c : 0.f;
       const float half = ok ? 0.5f * (hi[0] - lo[0]) : INFINITY;
       radius2 += half * half;
-      centre[9 + d] = half;
+      centre[FAST_AUX_HALF + d] = half;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) centre[8] = radius2;
+  if (threadIdx.x == 0) centre[FAST_AUX_RADIUS2] = radius2;
 }
 
 // exact three-way bf16 split of an fp32 value: v == hi + mid + lo

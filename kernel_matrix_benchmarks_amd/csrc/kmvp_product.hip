@@ -721,13 +721,16 @@ int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D) {
   c->cloud_radius2 = INFINITY;
   if (dtype != KMVP_F32 || D > FAST_MAX_D || M <= 0 || N <= 0) return KMVP_OK;
   int rc;
-  if ((rc = ensure(c, c->aux, 32 * sizeof(float)))) return rc;
-  hipLaunchKernelGGL(fast_center_kernel, dim3(1), dim3(1024), 0, c->stream, (const float*)c->y_raw.p, M,
-                     c->same_points ? (const float*)nullptr : (const float*)c->x_raw.p, N, D,
+  if ((rc = ensure(c, c->aux, (FAST_AUX_FLOATS + 2 * (size_t)FAST_BBOX_BLOCKS * D) * sizeof(float)))) return rc;
+  float* part = (float*)c->aux.p + FAST_AUX_FLOATS;
+  hipLaunchKernelGGL(fast_bbox_partial_kernel, dim3(FAST_BBOX_BLOCKS), dim3(256), 0, c->stream,
+                     (const float*)c->y_raw.p, M, c->same_points ? (const float*)nullptr : (const float*)c->x_raw.p, N,
+                     D, part);
+  hipLaunchKernelGGL(fast_center_kernel, dim3(1), dim3(FAST_BBOX_BLOCKS), 0, c->stream, (const float*)part, D,
                      (float*)c->aux.p);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(&c->cloud_radius2, (float*)c->aux.p + 8, sizeof(float), hipMemcpyDeviceToHost,
-                            c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&c->cloud_radius2, (float*)c->aux.p + FAST_AUX_RADIUS2, sizeof(float),
+                            hipMemcpyDeviceToHost, c->stream));
   c->centre_ver = c->points_ver + 1;  // kmvp_set_points bumps points_ver once the upload is complete
   return KMVP_OK;
 }

@@ -166,6 +166,16 @@ def test_clusters_far_apart_and_non_finite_points():
             assert extra["device_kernel"] == ("lowd_kernel" if opts else "cfast_kernel")
             assert rel_err(got, want) <= TOL32, (kernel, extra["device_kernel"], rel_err(got, want))
 
+    # mid-dimensional cloud far from the origin: every one of the D bounding-box centres has to be right
+    # for the global-centre expansion (D = 20 > 8 once overran the layout of the centre buffer)
+    yd = rs.rand(2000, 20) / np.sqrt(20.0) + 1.0e3
+    bd = rs.randn(2000, 1)
+    yd32 = yd.astype(np.float32).astype(np.float64)
+    want = kmvp_oracle.product(kernel="gaussian", source_points=yd32, source_signal=bd)
+    got, extra = run_plugin(dict(kernel="gaussian", D=20), yd, None, bd, "float32")
+    assert extra["device_kernel"] == "fast_kernel"
+    assert rel_err(got, want) <= TOL32, rel_err(got, want)
+
     y = rs.rand(1500, 3)
     y[7] = np.inf
     x = rs.rand(700, 3)
