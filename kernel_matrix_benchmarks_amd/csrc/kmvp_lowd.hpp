@@ -465,6 +465,84 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
 // ---------------------------------------------------------------------------------
 // layout + epilogue kernels (HBM-bound, tiny next to the pair loop)
 
+// Middle ground between the specialised kernel (D <= 8, compile-time D) and the generic one:
+// D <= 64 with BOTH clouds padded with zero coordinates to rows of 8 DCH entries (pad_rows_kernel), so
+// that the loop over dimensions has a compile-time length and no guards: the target's coordinates
+// live in REGISTERS (the generic kernel re-reads them from LDS for every pair), a source row arrives
+// through wave-uniform loads (scalar cache), fp32 sums are folded into fp64 every MID_CHUNK sources,
+// signal columns go in blocks of 8.
+constexpr int MID_CHUNK = 64;
+
+template <int KERNEL, int SIG, typename real, int DCH>
+__global__ void __launch_bounds__(BLOCK_THREADS) lowd_mid_kernel(
+    const real* __restrict__ x /* (N, 8 DCH) */, const real* __restrict__ y /* (M, 8 DCH) */,
+    const real* __restrict__ b /* (M, EP), EP = 8 ceil(E / 8), zero padded; unused for density */,
+    double* __restrict__ part, int64_t n, int64_t n_pad, int64_t m, int E, int EP, int NE, int segments,
+    int64_t seg_len, int64_t j_offset, int64_t m_total) {
+  constexpr int DMAX = 8 * DCH;
+  __shared__ double exp_tab_lds[sizeof(real) == 4 ? 1 : 64];
+  const double* exp_tab = exp_tab_lds;
+  if constexpr (sizeof(real) == 8) {
+    if (threadIdx.x < 64) exp_tab_lds[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+  }
+  const int seg = (int)(blockIdx.x % segments);
+  const int64_t tb = blockIdx.x / segments;
+  const int64_t i = tb * BLOCK_THREADS + threadIdx.x;
+  const int64_t ic = i < n ? i : n - 1;
+  real xr[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) xr[d] = x[ic * DMAX + d];
+  int64_t jz = -1;
+  if constexpr (KERNEL == K_INVDIST) {
+    const int64_t g = ic % (m_total + 1);
+    jz = (g < m_total) ? g - j_offset : (int64_t)-1;
+  }
+  const int64_t j0 = (int64_t)seg * seg_len;
+  int64_t j1 = j0 + seg_len;
+  if (j1 > m) j1 = m;
+  const int blocks = (SIG == SIG_DENSITY) ? 1 : EP / 8;  // passes over the sources, 8 signal columns each
+  for (int blk = 0; blk < blocks; ++blk) {
+    double accd[8], dend = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) accd[q] = 0.0;
+    for (int64_t jc = j0; jc < j1; jc += MID_CHUNK) {
+      const int64_t jend = jc + MID_CHUNK < j1 ? jc + MID_CHUNK : j1;
+      real acc[8], den = (real)0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = (real)0;
+      for (int64_t j = jc; j < jend; ++j) {
+        const real* __restrict__ yrow = y + j * DMAX;  // wave-uniform address
+        real s = 0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+          const real df = xr[d] - yrow[d];  // padded dimensions: 0 - 0
+          s = fma(df, df, s);
+        }
+        real k = kval<KERNEL>(s, exp_tab);
+        if constexpr (KERNEL == K_INVDIST) k = (j == jz) ? (real)0 : k;
+        if constexpr (SIG != SIG_DENSITY) {
+          const real* __restrict__ brow = b + j * EP + 8 * blk;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[q] = fma(k, brow[q], acc[q]);  // padded columns: k * 0
+        }
+        if constexpr (SIG != SIG_PRODUCT) den += k;  // denominator / density
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) accd[q] += (double)acc[q];
+      dend += (double)den;
+    }
+    if (i < n_pad) {
+      if constexpr (SIG != SIG_DENSITY) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (8 * blk + q < E) part[((int64_t)seg * NE + 8 * blk + q) * n_pad + i] = accd[q];
+      }
+      if (SIG != SIG_PRODUCT && blk == 0) part[((int64_t)seg * NE + (NE - 1)) * n_pad + i] = dend;
+    }
+  }
+}
+
 // targets (N,D) row-major -> SoA xs[d*n_pad + i] * scale ; pad targets are 0
 template <typename real>
 __global__ void pack_targets_kernel(const real* __restrict__ x, real* __restrict__ xs, int64_t n,
@@ -487,6 +565,16 @@ __global__ void pack_sources_kernel(const real* __restrict__ y, const real* __re
   for (int d = 0; d < D; ++d) r[d] = j < m ? y[j * D + d] * scale : (real)INFINITY;
   for (int e = 0; e < EB; ++e) r[D + e] = j < m ? b[j * ldb + col0 + e] : (real)0;
   for (int q = D + EB; q < R; ++q) r[q] = (real)0;
+}
+
+// out[r][d] = d < D ? in[r][d] : 0 for d < DP (rows padded with zero coordinates)
+template <typename real>
+__global__ void pad_rows_kernel(const real* __restrict__ in, real* __restrict__ out, int64_t rows, int D, int DP) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= rows * DP) return;
+  const int64_t r = q / DP;
+  const int d = (int)(q % DP);
+  out[q] = d < D ? in[r * D + d] : (real)0;
 }
 
 template <typename real>

@@ -97,6 +97,32 @@ hipError_t KMVP_CAT(KMVP_FN, _generic)(int sig, const real* x, const real* y, co
                                        int64_t j_offset, int64_t m_total, hipStream_t stream,
                                        const char** kernel_name) {
   const dim3 grid((unsigned)((n_pad / BLOCK_THREADS) * segments));
+  if (D <= 64) {  // coordinates in registers; x, y and b arrive padded to rows of 8 ceil(. / 8) entries
+    if (kernel_name) *kernel_name = "lowd_mid_kernel";
+#define KMVP_MID(SIGV, DCH)                                                                                   \
+  hipLaunchKernelGGL((lowd_mid_kernel<KERNEL, SIGV, real, DCH>), grid, dim3(BLOCK_THREADS), 0, stream, x, y, b, \
+                     part, n, n_pad, m, E, (E + 7) / 8 * 8, NE, segments, seg_len, j_offset, m_total)
+#define KMVP_MID_D(SIGV)                \
+  switch ((D + 7) / 8) {                \
+    case 1: KMVP_MID(SIGV, 1); break;   \
+    case 2: KMVP_MID(SIGV, 2); break;   \
+    case 3: KMVP_MID(SIGV, 3); break;   \
+    case 4: KMVP_MID(SIGV, 4); break;   \
+    case 5: KMVP_MID(SIGV, 5); break;   \
+    case 6: KMVP_MID(SIGV, 6); break;   \
+    case 7: KMVP_MID(SIGV, 7); break;   \
+    default: KMVP_MID(SIGV, 8); break;  \
+  }
+    switch (sig) {
+      case SIG_PRODUCT: KMVP_MID_D(SIG_PRODUCT); break;
+      case SIG_NORM: KMVP_MID_D(SIG_NORM); break;
+      case SIG_DENSITY: KMVP_MID_D(SIG_DENSITY); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef KMVP_MID_D
+#undef KMVP_MID
+    return hipGetLastError();
+  }
   size_t lds = (size_t)D * BLOCK_THREADS * sizeof(real);
   const int x_in_lds = lds <= 64 * 1024 ? 1 : 0;  // larger D: the target row is re-read through L1
   if (!x_in_lds) lds = 0;

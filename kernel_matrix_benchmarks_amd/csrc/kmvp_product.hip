@@ -331,14 +331,17 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   } else {
     // generic fallback: scaled copies of the points, one target per lane
     n_pad = round_up(std::max<int64_t>(N, 1), BLOCK_THREADS);
+    // D <= 64: lowd_mid_kernel wants both clouds as rows of DP = 8 ceil(D / 8) entries, zero padded;
+    // beyond, lowd_generic_kernel takes plain copies
+    const int DP = D <= 64 ? (D + 7) / 8 * 8 : D;
     if (c->gen_points_ver != c->points_ver || c->gen_kernel != kernel) {
-      if ((rc = ensure(c, c->y_scaled, (size_t)M * D * sizeof(real)))) return rc;
-      hipLaunchKernelGGL((scale_kernel<real>), dim3(blocks_for(M * D)), dim3(256), 0, c->stream,
-                         (const real*)c->y_raw.p, (real*)c->y_scaled.p, M * D, scale);
+      if ((rc = ensure(c, c->y_scaled, (size_t)M * DP * sizeof(real)))) return rc;
+      hipLaunchKernelGGL((pad_rows_kernel<real>), dim3(blocks_for(M * DP)), dim3(256), 0, c->stream,
+                         (const real*)c->y_raw.p, (real*)c->y_scaled.p, M, D, DP);
       if (!c->same_points) {
-        if ((rc = ensure(c, c->x_scaled, (size_t)N * D * sizeof(real)))) return rc;
-        hipLaunchKernelGGL((scale_kernel<real>), dim3(blocks_for(N * D)), dim3(256), 0, c->stream,
-                           x_raw, (real*)c->x_scaled.p, N * D, scale);
+        if ((rc = ensure(c, c->x_scaled, (size_t)N * DP * sizeof(real)))) return rc;
+        hipLaunchKernelGGL((pad_rows_kernel<real>), dim3(blocks_for(N * DP)), dim3(256), 0, c->stream, x_raw,
+                           (real*)c->x_scaled.p, N, D, DP);
       }
       HIP_TRY(c, hipGetLastError());
       c->gen_points_ver = c->points_ver;
@@ -350,9 +353,18 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     segments = (int)((M + seg_len - 1) / seg_len);
     if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
     const real* xg = (const real*)(c->same_points ? c->y_scaled.p : c->x_scaled.p);
+    const real* bg = sig == SIG_DENSITY ? nullptr : (const real*)c->b_raw.p;
+    if (D <= 64 && sig != SIG_DENSITY) {  // signal rows padded to whole blocks of 8 columns
+      const int EP = (c->E + 7) / 8 * 8;
+      if ((rc = ensure(c, c->rec, (size_t)M * EP * sizeof(real)))) return rc;
+      hipLaunchKernelGGL((pad_rows_kernel<real>), dim3(blocks_for(M * EP)), dim3(256), 0, c->stream,
+                         (const real*)c->b_raw.p, (real*)c->rec.p, M, c->E, EP);
+      HIP_TRY(c, hipGetLastError());
+      c->packed_layout = -1;  // rec no longer holds a specialised layout
+      bg = (const real*)c->rec.p;
+    }
     HIP_TRY(c, mark(c, 0));
-    HIP_TRY(c, launch_generic<real>(kernel, sig, xg, (const real*)c->y_scaled.p,
-                                    sig == SIG_DENSITY ? nullptr : (const real*)c->b_raw.p,
+    HIP_TRY(c, launch_generic<real>(kernel, sig, xg, (const real*)c->y_scaled.p, bg,
                                     (double*)c->part.p, N, n_pad, M, D, c->E, NE, segments, seg_len,
                                     c->j_offset, c->m_total, c->stream, &c->last_kernel_name));
   }
