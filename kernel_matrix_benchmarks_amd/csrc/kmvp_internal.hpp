@@ -72,6 +72,7 @@ hipError_t launch_fast_invdist(int D, int sig, int TT, const FastArgs& args, dim
 // centred split-bf16 MFMA path (kmvp_cfast.hpp): D <= 4, E == 1, every kernel
 constexpr int CFAST_MAX_D = 4;
 constexpr int CFAST_DEFAULT_TT = 2;
+constexpr int LOWD_MID_MAX_D = 128;  // lowd_mid_kernel: coordinates in registers up to here (16 chunks of 8)
 constexpr int64_t SMALL_PROBLEM_TARGETS = 32768;  // below: one target tile per wave, one stage per segment
 struct CfastArgs;
 hipError_t launch_cfast_gaussian(int sig, int TT, const CfastArgs& args, dim3 grid, hipStream_t stream,

@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
 // layout + epilogue kernels (HBM-bound, tiny next to the pair loop)
 
 // Middle ground between the specialised kernel (D <= 8, compile-time D) and the generic one:
-// D <= 64 with BOTH clouds padded with zero coordinates to rows of 8 DCH entries (pad_rows_kernel), so
+// D <= 128 with BOTH clouds padded with zero coordinates to rows of 8 DCH entries (pad_rows_kernel), so
 // that the loop over dimensions has a compile-time length and no guards: the target's coordinates
 // live in REGISTERS (the generic kernel re-reads them from LDS for every pair), a source row arrives
 // through wave-uniform loads (scalar cache), fp32 sums are folded into fp64 every MID_CHUNK sources,

@@ -97,7 +97,7 @@ hipError_t KMVP_CAT(KMVP_FN, _generic)(int sig, const real* x, const real* y, co
                                        int64_t j_offset, int64_t m_total, hipStream_t stream,
                                        const char** kernel_name) {
   const dim3 grid((unsigned)((n_pad / BLOCK_THREADS) * segments));
-  if (D <= 64) {  // coordinates in registers; x, y and b arrive padded to rows of 8 ceil(. / 8) entries
+  if (D <= LOWD_MID_MAX_D) {  // coordinates in registers; x, y and b arrive padded to rows of 8 ceil(. / 8) entries
     if (kernel_name) *kernel_name = "lowd_mid_kernel";
 #define KMVP_MID(SIGV, DCH)                                                                                   \
   hipLaunchKernelGGL((lowd_mid_kernel<KERNEL, SIGV, real, DCH>), grid, dim3(BLOCK_THREADS), 0, stream, x, y, b, \
@@ -111,7 +111,15 @@ hipError_t KMVP_CAT(KMVP_FN, _generic)(int sig, const real* x, const real* y, co
     case 5: KMVP_MID(SIGV, 5); break;   \
     case 6: KMVP_MID(SIGV, 6); break;   \
     case 7: KMVP_MID(SIGV, 7); break;   \
-    default: KMVP_MID(SIGV, 8); break;  \
+    case 8: KMVP_MID(SIGV, 8); break;   \
+    case 9: KMVP_MID(SIGV, 9); break;   \
+    case 10: KMVP_MID(SIGV, 10); break; \
+    case 11: KMVP_MID(SIGV, 11); break; \
+    case 12: KMVP_MID(SIGV, 12); break; \
+    case 13: KMVP_MID(SIGV, 13); break; \
+    case 14: KMVP_MID(SIGV, 14); break; \
+    case 15: KMVP_MID(SIGV, 15); break; \
+    default: KMVP_MID(SIGV, 16); break; \
   }
     switch (sig) {
       case SIG_PRODUCT: KMVP_MID_D(SIG_PRODUCT); break;
