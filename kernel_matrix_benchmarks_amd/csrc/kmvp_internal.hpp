@@ -14,7 +14,7 @@ struct LowdTuning {
 };
 
 // Largest shapes the specialised kernels are instantiated for; anything else goes
-// to lowd_generic_kernel (or to the MFMA path for bf16).
+// to lowd_mid_kernel / lowd_big_kernel (or to the MFMA path for bf16).
 constexpr int LOWD_MAX_D = 8;
 constexpr int LOWD_MAX_E = 4;
 

@@ -392,83 +392,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_kernel(const LowdArgs<real
 }
 
 // ---------------------------------------------------------------------------------
-// generic fallback: any D, any E (runtime), one target per lane, coordinates of the
-// lane's target in LDS, signal columns in blocks of 8 (the kernel value is
-// recomputed per block).  Correct for every shape; only the specialised kernels
-// above are tuned.
-template <int KERNEL, int SIG, typename real>
-__global__ void __launch_bounds__(BLOCK_THREADS) lowd_generic_kernel(
-    const real* __restrict__ x,  // (N,D) row-major, scaled
-    const real* __restrict__ y,  // (M,D) row-major, scaled
-    const real* __restrict__ b,  // (M,E) row-major or null
-    double* __restrict__ part,   // [segments][NE][n_pad]
-    int64_t n, int64_t n_pad, int64_t m, int D, int E, int NE, int segments, int64_t seg_len,
-    int64_t j_offset, int64_t m_total, int x_in_lds) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  real* xl = reinterpret_cast<real*>(dyn_lds);  // [D][BLOCK_THREADS] when it fits in LDS
-  __shared__ double exp_tab_lds[sizeof(real) == 4 ? 1 : 64];
-  const double* exp_tab = exp_tab_lds;
-  if constexpr (sizeof(real) == 8) {
-    if (threadIdx.x < 64) exp_tab_lds[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
-    __syncthreads();
-  }
-  const int seg = (int)(blockIdx.x % segments);
-  const int64_t tb = blockIdx.x / segments;
-  const int64_t i = tb * BLOCK_THREADS + threadIdx.x;
-  const int64_t ic = i < n ? i : n - 1;
-  if (x_in_lds)
-    for (int d = 0; d < D; ++d) xl[d * BLOCK_THREADS + threadIdx.x] = x[ic * D + d];
-  const real* __restrict__ xrow = x + ic * D;
-  int64_t jz = -1;
-  if constexpr (KERNEL == K_INVDIST) {
-    const int64_t g = ic % (m_total + 1);
-    jz = (g < m_total) ? g - j_offset : (int64_t)-1;
-  }
-  const int64_t j0 = (int64_t)seg * seg_len;
-  int64_t j1 = j0 + seg_len;
-  if (j1 > m) j1 = m;
-  const int EB = (SIG == SIG_DENSITY) ? 0 : E;
-  for (int e0 = 0; e0 < NE; e0 += 8) {
-    double acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-    for (int64_t j = j0; j < j1; ++j) {
-      real s = 0;
-      if (x_in_lds) {
-        for (int d = 0; d < D; ++d) {
-          const real df = xl[d * BLOCK_THREADS + threadIdx.x] - y[j * D + d];
-          s = fma(df, df, s);
-        }
-      } else {
-        for (int d = 0; d < D; ++d) {
-          const real df = xrow[d] - y[j * D + d];
-          s = fma(df, df, s);
-        }
-      }
-      real k = kval<KERNEL>(s, exp_tab);
-      if constexpr (KERNEL == K_INVDIST) k = (j == jz) ? (real)0 : k;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int e = e0 + q;
-        if (e < EB) acc[q] += (double)(k * b[j * E + e]);
-        else if (e < NE) acc[q] += (double)k;  // denominator column / density
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int e = e0 + q;
-      if (e < NE && i < n_pad) part[((int64_t)seg * NE + e) * n_pad + i] = acc[q];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------
 // layout + epilogue kernels (HBM-bound, tiny next to the pair loop)
 
-// Middle ground between the specialised kernel (D <= 8, compile-time D) and the generic one:
+// Beyond the specialised kernel (D <= 8, compile-time D):
 // D <= 128 with BOTH clouds padded with zero coordinates to rows of 8 DCH entries (pad_rows_kernel), so
 // that the loop over dimensions has a compile-time length and no guards: the target's coordinates
-// live in REGISTERS (the generic kernel re-reads them from LDS for every pair), a source row arrives
+// live in REGISTERS, a source row arrives
 // through wave-uniform loads (scalar cache), fp32 sums are folded into fp64 every MID_CHUNK sources,
 // signal columns go in blocks of 8.
 constexpr int MID_CHUNK = 64;
@@ -532,6 +461,107 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_mid_kernel(
       for (int q = 0; q < 8; ++q) accd[q] += (double)acc[q];
       dend += (double)den;
     }
+    if (i < n_pad) {
+      if constexpr (SIG != SIG_DENSITY) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (8 * blk + q < E) part[((int64_t)seg * NE + 8 * blk + q) * n_pad + i] = accd[q];
+      }
+      if (SIG != SIG_PRODUCT && blk == 0) part[((int64_t)seg * NE + (NE - 1)) * n_pad + i] = dend;
+    }
+  }
+}
+
+// Any D beyond LOWD_MID_MAX_D: the same padded rows (to multiples of BIG_CHUNK coordinates), walked in
+// chunks of BIG_CHUNK dimensions for a batch of BIG_BATCH sources at a time -- the target's chunk sits in
+// registers (reloaded per batch from its own row, L1/L2 resident), the squared distances of the batch
+// accumulate in registers across the chunks, source chunks arrive through wave-uniform loads.
+constexpr int BIG_CHUNK = 32;
+constexpr int BIG_BATCH = 8;
+
+template <int KERNEL, int SIG, typename real>
+__global__ void __launch_bounds__(BLOCK_THREADS) lowd_big_kernel(
+    const real* __restrict__ x /* (N, DP) */, const real* __restrict__ y /* (M, DP) */,
+    const real* __restrict__ b /* (M, EP), zero padded; unused for density */, double* __restrict__ part, int64_t n,
+    int64_t n_pad, int64_t m, int DP, int E, int EP, int NE, int segments, int64_t seg_len, int64_t j_offset,
+    int64_t m_total) {
+  __shared__ double exp_tab_lds[sizeof(real) == 4 ? 1 : 64];
+  const double* exp_tab = exp_tab_lds;
+  if constexpr (sizeof(real) == 8) {
+    if (threadIdx.x < 64) exp_tab_lds[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+  }
+  const int seg = (int)(blockIdx.x % segments);
+  const int64_t tb = blockIdx.x / segments;
+  const int64_t i = tb * BLOCK_THREADS + threadIdx.x;
+  const int64_t ic = i < n ? i : n - 1;
+  const real* __restrict__ xrow = x + ic * DP;
+  int64_t jz = -1;
+  if constexpr (KERNEL == K_INVDIST) {
+    const int64_t g = ic % (m_total + 1);
+    jz = (g < m_total) ? g - j_offset : (int64_t)-1;
+  }
+  const int64_t j0 = (int64_t)seg * seg_len;
+  int64_t j1 = j0 + seg_len;
+  if (j1 > m) j1 = m;
+  const int blocks = (SIG == SIG_DENSITY) ? 1 : EP / 8;
+  for (int blk = 0; blk < blocks; ++blk) {
+    double accd[8], dend = 0.0;
+    real acc[8], den = (real)0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      accd[q] = 0.0;
+      acc[q] = (real)0;
+    }
+    int in_chunk = 0;
+    for (int64_t j = j0; j < j1; j += BIG_BATCH) {
+      real sb[BIG_BATCH];
+#pragma unroll
+      for (int jj = 0; jj < BIG_BATCH; ++jj) sb[jj] = (real)0;
+      for (int c = 0; c < DP; c += BIG_CHUNK) {
+        real xr[BIG_CHUNK];
+#pragma unroll
+        for (int d = 0; d < BIG_CHUNK; ++d) xr[d] = xrow[c + d];
+#pragma unroll
+        for (int jj = 0; jj < BIG_BATCH; ++jj) {
+          const int64_t jr = j + jj < j1 ? j + jj : j1 - 1;  // past the end: a valid row, its value is dropped below
+          const real* __restrict__ yrow = y + jr * DP + c;   // wave-uniform address
+          real s = sb[jj];
+#pragma unroll
+          for (int d = 0; d < BIG_CHUNK; ++d) {
+            const real df = xr[d] - yrow[d];
+            s = fma(df, df, s);
+          }
+          sb[jj] = s;
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < BIG_BATCH; ++jj) {
+        if (j + jj < j1) {  // wave-uniform
+          real k = kval<KERNEL>(sb[jj], exp_tab);
+          if constexpr (KERNEL == K_INVDIST) k = (j + jj == jz) ? (real)0 : k;
+          if constexpr (SIG != SIG_DENSITY) {
+            const real* __restrict__ brow = b + (j + jj) * EP + 8 * blk;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = fma(k, brow[q], acc[q]);
+          }
+          if constexpr (SIG != SIG_PRODUCT) den += k;
+        }
+      }
+      if (++in_chunk == MID_CHUNK / BIG_BATCH) {
+        in_chunk = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          accd[q] += (double)acc[q];
+          acc[q] = (real)0;
+        }
+        dend += (double)den;
+        den = (real)0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) accd[q] += (double)acc[q];
+    dend += (double)den;
     if (i < n_pad) {
       if constexpr (SIG != SIG_DENSITY) {
 #pragma unroll

@@ -131,30 +131,21 @@ hipError_t KMVP_CAT(KMVP_FN, _generic)(int sig, const real* x, const real* y, co
 #undef KMVP_MID
     return hipGetLastError();
   }
-  size_t lds = (size_t)D * BLOCK_THREADS * sizeof(real);
-  const int x_in_lds = lds <= 64 * 1024 ? 1 : 0;  // larger D: the target row is re-read through L1
-  if (!x_in_lds) lds = 0;
-  if (kernel_name) *kernel_name = "lowd_generic_kernel";
-  switch (sig) {
-    case SIG_PRODUCT:
-      hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_PRODUCT, real>), grid, dim3(BLOCK_THREADS),
-                         lds, stream, x, y, b, part, n, n_pad, m, D, E, NE, segments, seg_len,
-                         j_offset, m_total, x_in_lds);
-      break;
-    case SIG_NORM:
-      hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_NORM, real>), grid, dim3(BLOCK_THREADS),
-                         lds, stream, x, y, b, part, n, n_pad, m, D, E, NE, segments, seg_len,
-                         j_offset, m_total, x_in_lds);
-      break;
-    case SIG_DENSITY:
-      hipLaunchKernelGGL((lowd_generic_kernel<KERNEL, SIG_DENSITY, real>), grid,
-                         dim3(BLOCK_THREADS), lds, stream, x, y, b, part, n, n_pad, m, D, E, NE,
-                         segments, seg_len, j_offset, m_total, x_in_lds);
-      break;
-    default:
-      return hipErrorInvalidValue;
+  {  // any larger D: chunked walk over padded rows (x, y padded to 32 ceil(D / 32), b to 8 ceil(E / 8))
+    if (kernel_name) *kernel_name = "lowd_big_kernel";
+    const int DP = (D + BIG_CHUNK - 1) / BIG_CHUNK * BIG_CHUNK, EP = (E + 7) / 8 * 8;
+#define KMVP_BIG(SIGV)                                                                                         \
+  hipLaunchKernelGGL((lowd_big_kernel<KERNEL, SIGV, real>), grid, dim3(BLOCK_THREADS), 0, stream, x, y, b, part, \
+                     n, n_pad, m, DP, E, EP, NE, segments, seg_len, j_offset, m_total)
+    switch (sig) {
+      case SIG_PRODUCT: KMVP_BIG(SIG_PRODUCT); break;
+      case SIG_NORM: KMVP_BIG(SIG_NORM); break;
+      case SIG_DENSITY: KMVP_BIG(SIG_DENSITY); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef KMVP_BIG
+    return hipGetLastError();
   }
-  return hipGetLastError();
 }
 
 }  // namespace kmvp

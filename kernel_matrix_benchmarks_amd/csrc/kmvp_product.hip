@@ -331,9 +331,9 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
   } else {
     // generic fallback: scaled copies of the points, one target per lane
     n_pad = round_up(std::max<int64_t>(N, 1), BLOCK_THREADS);
-    // D <= LOWD_MID_MAX_D: lowd_mid_kernel wants both clouds as rows of DP = 8 ceil(D / 8) entries, zero padded;
-    // beyond, lowd_generic_kernel takes plain copies
-    const int DP = D <= LOWD_MID_MAX_D ? (D + 7) / 8 * 8 : D;
+    // both clouds as rows of DP entries, zero padded: 8 ceil(D / 8) for lowd_mid_kernel, 32 ceil(D / 32) for
+    // lowd_big_kernel
+    const int DP = D <= LOWD_MID_MAX_D ? (D + 7) / 8 * 8 : (D + 31) / 32 * 32;  // lowd_big_kernel: chunks of 32
     if (c->gen_points_ver != c->points_ver || c->gen_kernel != kernel) {
       if ((rc = ensure(c, c->y_scaled, (size_t)M * DP * sizeof(real)))) return rc;
       hipLaunchKernelGGL((pad_rows_kernel<real>), dim3(blocks_for(M * DP)), dim3(256), 0, c->stream,
@@ -354,7 +354,7 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
     const real* xg = (const real*)(c->same_points ? c->y_scaled.p : c->x_scaled.p);
     const real* bg = sig == SIG_DENSITY ? nullptr : (const real*)c->b_raw.p;
-    if (D <= LOWD_MID_MAX_D && sig != SIG_DENSITY) {  // signal rows padded to whole blocks of 8 columns
+    if (sig != SIG_DENSITY) {  // signal rows padded to whole blocks of 8 columns
       const int EP = (c->E + 7) / 8 * 8;
       if ((rc = ensure(c, c->rec, (size_t)M * EP * sizeof(real)))) return rc;
       hipLaunchKernelGGL((pad_rows_kernel<real>), dim3(blocks_for(M * EP)), dim3(256), 0, c->stream,

@@ -229,6 +229,37 @@ def test_random_shapes_flags_and_precisions():
                                           rel_err(got, want))
 
 
+def test_dimensions_beyond_128():
+    """D > 128 (lowd_big_kernel: rows padded to multiples of 32 coordinates, chunked walk): ragged D and
+    E, every query() branch, both precisions, batches of sources that end inside a segment."""
+    rs = np.random.RandomState(129)
+    shapes = [(129, 1), (160, 3), (200, 9), (257, 8), (300, 17), (1000, 1)]
+    for case_no, (D, E) in enumerate(shapes * 2):
+        kernel = golden_cases.KERNELS[case_no % 3]
+        M = int(rs.choice([1, 7, 9, 333, 1030]))
+        same = bool(case_no % 2)
+        N = M if same else int(rs.choice([1, 65, 300]))
+        norm = bool(case_no % 3 == 1)
+        dens = bool(case_no % 5 == 4)
+        prec = "float64" if case_no >= len(shapes) else "float32"
+        scale = 1.0 / np.sqrt(D / 3.0)
+        y = rs.rand(M, D) * scale
+        x = None if same else rs.rand(N, D) * scale
+        b = None if dens else rs.randn(M, E)
+        if prec == "float32":
+            y = y.astype(np.float32).astype(np.float64)
+            x = None if x is None else x.astype(np.float32).astype(np.float64)
+            b = None if b is None else b.astype(np.float32).astype(np.float64)
+        want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b,
+                                   normalize_rows=norm, density_estimation=dens)
+        got, extra = run_plugin(dict(kernel=kernel, D=D, normalize_rows=norm), y, x, b, prec)
+        if not (norm and dens):  # normalised density is all ones without a launch
+            assert extra["device_kernel"] == "lowd_big_kernel", extra
+        assert got.shape == want.shape
+        tol = TOL64 if prec == "float64" else 2e-5
+        assert rel_err(got, want) <= tol, (case_no, kernel, D, E, N, M, same, norm, dens, prec, rel_err(got, want))
+
+
 def test_random_options_never_break_a_product():
     """Seeded sweep over the tuning options (segments, tiles per wave, forced squared-distance forms,
     feeds): options that do not apply fall back silently, every combination returns the right sums

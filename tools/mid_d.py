@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from kernel_matrix_benchmarks_amd import _lib
 n = 100000
 rs = np.random.RandomState(1)
-for D in (3, 8, 16, 39, 40, 64, 100, 128, 129):
+for D in (3, 8, 16, 39, 40, 64, 100, 128, 129, 160, 256, 512):
     y = (rs.rand(n, D) / np.sqrt(D)).astype(np.float32); b = rs.randn(n, 1).astype(np.float32)
     for prec, code in (("f32", _lib.KMVP_F32), ("bf16", _lib.KMVP_BF16)):
         if prec == "bf16" and (D < 16 or D > 128): continue
