@@ -22,7 +22,7 @@
 namespace kmvp {
 
 // which path's layouts the shared xs / rec buffers hold
-enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2, LAYOUT_CFAST = 3 };
+enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2, LAYOUT_CFAST = 3, LAYOUT_CELL = 4 };
 
 struct DevBuf {
   void* p = nullptr;
@@ -107,6 +107,9 @@ struct kmvp_ctx {
   DevBuf aux;                   // cloud centre, squared radius, half-widths (fast_center_kernel)
   DevBuf sortbuf, perm;         // centred path: radix-sort scratch, Morton order of the sources
   DevBuf x_scaled, y_scaled;    // scaled copies (generic path)
+  // cell-reduced Gaussian path (kmvp_cell.hpp): cell order of targets / sources, their tiles
+  // ([start][count][key] per tile), slot of every target in cell order, target tile centres
+  DevBuf cell_tperm, cell_sperm, cell_tgrp, cell_sgrp, cell_slot, cell_tmeta;
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
   DevBuf xchg;                  // sharded runs: sums in the canonical unpadded layout [column][N] for the all-reduce
   DevBuf scratch;               // CG vectors / dot products
@@ -122,9 +125,14 @@ struct kmvp_ctx {
 
   // tuning (kmvp_set_option)
   int opt_feed = -1, opt_T = 0, opt_segments = 0, opt_chunk = 512;
-  int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always, 2 always the centred form
+  int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always, 2 always the centred form, 3 always the cell form
   int opt_same_global = 0;                // the targets ARE the (unsharded) sources although x was passed explicitly
   uint64_t perm_ver = 0;                  // points version the Morton order belongs to
+  uint64_t cell_ver = 0;                  // points version the cell structures belong to
+  int cell_state = 0;                     // for cell_ver: 0 not examined, 1 built, -1 the path does not apply
+  float cell_lo[3] = {0.f, 0.f, 0.f}, cell_h = 0.f;
+  int cell_g[3] = {1, 1, 1};
+  int64_t cell_n_tiles = 0, cell_m_tiles = 0;  // real tiles of 32 (targets / sources)
   float cloud_radius2 = INFINITY;          // squared half-diagonal of the clouds' bounding box
   uint64_t centre_ver = 0;
 

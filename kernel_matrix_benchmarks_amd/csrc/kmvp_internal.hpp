@@ -81,6 +81,14 @@ hipError_t launch_cfast_absexp(int sig, int TT, const CfastArgs& args, dim3 grid
                                const char** kernel_name);
 hipError_t launch_cfast_invdist(int sig, int TT, const CfastArgs& args, dim3 grid, hipStream_t stream,
                                 const char** kernel_name);
+// cell-reduced Gaussian path (kmvp_cell.hpp): float32, D <= 3, E == 1
+constexpr int CELL_MAX_D = 3;
+constexpr int CELL_DEFAULT_TT = 2;
+// auto mode: the path is taken when padding the cells' last tiles adds at most this share of slots
+constexpr double CELL_AUTO_MAX_PAD = 1.30;
+struct CellArgs;
+hipError_t launch_cell_gaussian(int sig, int TT, const CellArgs& args, dim3 grid, hipStream_t stream,
+                                const char** kernel_name);
 // kmvp_sort.hip: hipcub radix sort of (key, value) pairs; tmp == nullptr queries the scratch size
 hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const unsigned* keys_in, unsigned* keys_out,
                           const int* vals_in, int* vals_out, int64_t n, hipStream_t stream);

@@ -3,6 +3,8 @@
 //   segment reduction -> [RCCL all-reduce over the source shards] -> normalise.
 // Reference call this serves: BruteForceProductBLAS.query (bruteforce.py:130-153).
 #include "kmvp_ctx.hpp"
+#include <vector>
+#include "kmvp_cell_pack.hpp"
 #include "kmvp_cfast_pack.hpp"
 #include "kmvp_fast_pack.hpp"
 #include "kmvp_mfma_pack.hpp"
@@ -632,6 +634,188 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
 }
 
+// ---- cell-reduced Gaussian path (kmvp_cell.hpp): float32, D <= 3, E == 1 -----------------------------
+
+// Cell order of one cloud: keys -> radix sort -> tiles of <= 32 points that never straddle a cell.
+// The tile list is built on the host from the sorted keys (one pass over n keys, once per kmvp_set_points).
+int cell_order(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, kmvp_ctx::DevBuf& perm,
+               kmvp_ctx::DevBuf& grp, int64_t* n_tiles) {
+  int rc;
+  const int D = c->D;
+  size_t tmp_bytes = 0;
+  HIP_TRY(c, sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, c->stream));
+  const size_t keys_bytes = (size_t)n * sizeof(unsigned);
+  if ((rc = ensure(c, c->sortbuf, 3 * keys_bytes + tmp_bytes + 256))) return rc;
+  if ((rc = ensure(c, perm, (size_t)n * sizeof(int)))) return rc;
+  unsigned* keys_in = (unsigned*)c->sortbuf.p;
+  unsigned* keys_out = keys_in + n;
+  int* vals_in = (int*)(keys_out + n);
+  void* tmp = (void*)((((uintptr_t)(vals_in + n)) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(cell_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, pts, n, D, grid, keys_in, vals_in);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, sort_pairs_u32(tmp, &tmp_bytes, keys_in, keys_out, vals_in, (int*)perm.p, n, c->stream));
+  std::vector<unsigned> keys((size_t)n);
+  HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_out, keys_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<int> start, count;
+  std::vector<unsigned> gkey;
+  start.reserve((size_t)n / 24 + 16);
+  count.reserve((size_t)n / 24 + 16);
+  gkey.reserve((size_t)n / 24 + 16);
+  for (int64_t p = 0; p < n;) {
+    int64_t e = p + 1;
+    while (e < n && keys[(size_t)e] == keys[(size_t)p]) ++e;
+    for (int64_t t = p; t < e; t += CELL_TILE) {
+      start.push_back((int)t);
+      count.push_back((int)std::min<int64_t>(CELL_TILE, e - t));
+      gkey.push_back(keys[(size_t)p]);
+    }
+    p = e;
+  }
+  const size_t G = start.size();
+  if ((rc = ensure(c, grp, 3 * G * sizeof(int)))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(grp.p, start.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync((int*)grp.p + G, count.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync((int*)grp.p + 2 * G, gkey.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+  *n_tiles = (int64_t)G;
+  return KMVP_OK;
+}
+
+// Grid and cell order of both clouds for the current points (cached per points version).
+// Leaves c->cell_state = 1 when the path can run, -1 when it cannot (D > 3, non-finite box, more
+// than 1024 cells along an axis).
+int cell_prepare(kmvp_ctx* c) {
+  if (c->cell_ver == c->points_ver && c->cell_state != 0) return KMVP_OK;
+  c->cell_ver = c->points_ver;
+  c->cell_state = -1;
+  const int D = c->D;
+  if (D > CELL_MAX_D || !(c->cloud_radius2 < INFINITY) || c->N > 0x3fffffff || c->M > 0x3fffffff) return KMVP_OK;
+  float aux[FAST_AUX_FLOATS];
+  HIP_TRY(c, hipMemcpyAsync(aux, c->aux.p, sizeof(aux), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  CellGrid grid;
+  grid.h = std::sqrt(2.f * CELL_T_MAX / (float)D);  // |2 d.e| <= D h^2 / 2 <= CELL_T_MAX
+  grid.inv_h = 1.f / grid.h;
+  for (int a = 0; a < 3; ++a) {
+    grid.lo[a] = 0.f;
+    grid.g[a] = 1;
+  }
+  for (int a = 0; a < D; ++a) {
+    const float half = aux[FAST_AUX_HALF + a];
+    grid.lo[a] = aux[a] - half;
+    const double cells = std::floor(2.0 * half / grid.h) + 1.0;
+    if (!(cells <= CELL_MAX_GRID)) return KMVP_OK;
+    grid.g[a] = (int)cells;
+  }
+  int rc;
+  if ((rc = cell_order(c, (const float*)c->y_raw.p, c->M, grid, c->cell_sperm, c->cell_sgrp, &c->cell_m_tiles))) return rc;
+  if (c->same_points) {
+    c->cell_n_tiles = c->cell_m_tiles;
+  } else {
+    if ((rc = cell_order(c, (const float*)c->x_raw.p, c->N, grid, c->cell_tperm, c->cell_tgrp, &c->cell_n_tiles))) return rc;
+  }
+  for (int a = 0; a < 3; ++a) {
+    c->cell_lo[a] = grid.lo[a];
+    c->cell_g[a] = grid.g[a];
+  }
+  c->cell_h = grid.h;
+  c->cell_state = 1;
+  c->packed_layout = -1;  // xs / rec are re-packed by whoever runs next
+  return KMVP_OK;
+}
+
+// share of slots over points after padding the last tile of every cell (both clouds)
+double cell_padding(const kmvp_ctx* c) {
+  const double t = (double)c->cell_n_tiles * CELL_TILE / (double)std::max<int64_t>(c->N, 1);
+  const double s = (double)c->cell_m_tiles * CELL_TILE / (double)std::max<int64_t>(c->M, 1);
+  return std::max(t, s);
+}
+
+int run_product_cell(kmvp_ctx* c, int sig) {
+  const int D = c->D;
+  const int E = 1;
+  const int NE = sig == SIG_NORM ? 2 : 1;
+  const int64_t N = c->N;
+  const bool small = N < SMALL_PROBLEM_TARGETS;
+  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (small ? 1 : CELL_DEFAULT_TT);
+  const int64_t tiles_per_block_max = 4 * WAVES_PER_BLOCK;  // TT <= 4: the padded tile count suits every TT
+  const int64_t n_tiles = round_up(c->cell_n_tiles, tiles_per_block_max);
+  const int64_t n_slots = n_tiles * CELL_TILE;
+  const int64_t tile_blocks = n_tiles / (TT * WAVES_PER_BLOCK);
+  const int64_t m_stages = (c->cell_m_tiles + CELL_STAGE_TILES - 1) / CELL_STAGE_TILES;
+  int rc;
+  CellGrid grid;
+  for (int a = 0; a < 3; ++a) {
+    grid.lo[a] = c->cell_lo[a];
+    grid.g[a] = c->cell_g[a];
+  }
+  grid.h = c->cell_h;
+  grid.inv_h = 1.f / c->cell_h;
+
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_slots, CELL_STAGE_BYTES, small ? 1 : 4, small);
+  const int64_t seg_stages = (m_stages + segments - 1) / segments;
+  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
+                         c->packed_layout != LAYOUT_CELL;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int* tperm = (const int*)(c->same_points ? c->cell_sperm.p : c->cell_tperm.p);
+  const int* tgrp = (const int*)(c->same_points ? c->cell_sgrp.p : c->cell_tgrp.p);
+  const int* sgrp = (const int*)c->cell_sgrp.p;
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_slots * 4 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->cell_tmeta, (size_t)n_tiles * 4 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->cell_slot, (size_t)N * sizeof(int)))) return rc;
+    hipLaunchKernelGGL(pack_cell_targets_kernel, dim3((unsigned)n_tiles), dim3(CELL_TILE), 0, c->stream, x_raw, tperm,
+                       tgrp, tgrp + c->cell_n_tiles, (const unsigned*)(tgrp + 2 * c->cell_n_tiles), c->cell_n_tiles, D,
+                       grid, (float*)c->xs.p, (float*)c->cell_tmeta.p, (int*)c->cell_slot.p);
+  }
+  if (sig_stale) {
+    if ((rc = ensure(c, c->rec, (size_t)m_stages * CELL_STAGE_BYTES))) return rc;
+    hipLaunchKernelGGL(pack_cell_sources_kernel, dim3((unsigned)(m_stages * CELL_STAGE_TILES)), dim3(CELL_TILE), 0,
+                       c->stream, (const float*)c->y_raw.p,
+                       sig == SIG_DENSITY ? (const float*)nullptr : (const float*)c->b_raw.p,
+                       (const int*)c->cell_sperm.p, sgrp, sgrp + c->cell_m_tiles,
+                       (const unsigned*)(sgrp + 2 * c->cell_m_tiles), c->cell_m_tiles, D, grid,
+                       (unsigned char*)c->rec.p);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = K_GAUSSIAN;
+  c->packed_sig = sig;
+  c->packed_layout = LAYOUT_CELL;
+  c->packed_T = TT;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * NE * n_slots * sizeof(double)))) return rc;
+  CellArgs a;
+  a.xd = (const float*)c->xs.p;
+  a.tmeta = (const float*)c->cell_tmeta.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.part = (double*)c->part.p;
+  a.n_slots = n_slots;
+  a.m_stages = m_stages;
+  a.seg_stages = seg_stages;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.chunk_stages = std::max(1, c->opt_chunk / (CELL_TILE * CELL_STAGE_TILES));
+  const dim3 grid_dim((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, mark(c, 0));
+  hipError_t le = launch_cell_gaussian(sig, TT, a, grid_dim, c->stream, &c->last_kernel_name);
+  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
+  HIP_TRY(c, le);
+  HIP_TRY(c, mark(c, 1));
+
+  // ---- epilogue: segments -> sums in the caller's order, [all-reduce over the source shards], normalise
+  if ((rc = ensure(c, c->sums, (size_t)NE * N * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_cells_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, NE, segments);
+  HIP_TRY(c, hipGetLastError());
+  return finish_product(c, (int64_t)NE * N, N, N, E, sig);
+}
+
 // bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
 // to augmented bf16 rows / LDS tile images, sums come back as fp32 partials.
 int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
@@ -813,6 +997,14 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     const bool global_ok = kernel == K_GAUSSIAN && c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
     const bool same = c->same_points || c->opt_same_global;
     const bool centred_ok = c->D <= CFAST_MAX_D && (kernel != K_INVDIST || (same && c->N == c->m_total));
+    // cell_kernel: exp() range-reduced by grid cells, the polynomial remainder on the matrix cores
+    // (Gaussian, D <= 3).  auto: when the clouds fill the cells well enough that padding stays small.
+    if (kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->async_product &&
+        (c->opt_fast == 3 || (c->opt_fast < 0 && global_ok && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
+      int rc = cell_prepare(c);
+      if (rc) return rc;
+      if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) return run_product_cell(c, sig);
+    }
     if (c->opt_fast == 1 || (c->opt_fast < 0 && global_ok)) return run_product_fast(c, kernel, sig);
     if (centred_ok && (c->opt_fast == 2 || c->opt_fast < 0)) return run_product_cfast(c, kernel, sig);
   }
