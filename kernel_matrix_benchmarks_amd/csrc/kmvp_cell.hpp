@@ -24,8 +24,9 @@
 //
 // Cells come from one radix sort per cloud (cell index = key); inside a cell points form tiles of 32,
 // the last one padded (pad sources carry b = 0, pad targets are never read back).  Tiles of one
-// cell share their centre, so U is recomputed only when the source tile's cell changes and W only
-// for the distinct cells among a wave's target tiles.  Differences are formed from the caller's
+// cell share their centre, so U is recomputed only when the source tile's cell changes; the target
+// tiles of a cell are padded to a multiple of TT, so the TT tiles of a wave always share one cell and
+// W is computed (and read back from LDS) once per wave and source tile.  Differences are formed from the caller's
 // coordinates first (d = x - c_T in fp32 is exact to an ulp of d; D is the difference of the stored
 // fp32 centres), as on every other path.
 //
@@ -64,7 +65,7 @@ __host__ __device__ inline float cell_centre(unsigned key, int a, const CellGrid
 
 struct CellArgs {
   const float* xd;           // targets [n_slots][4]: d_x, d_y, d_z, 0 (cell-sorted, tiles padded)
-  const float* tmeta;        // target tiles [n_slots / 32][4]: c_x, c_y, c_z, cell key (bits)
+  const float* tmeta;        // target tiles [n_slots / 32][4]: c_x, c_y, c_z, cell key (bits; bit 30: empty tile)
   const unsigned char* img;  // source stages [m_stages][CELL_STAGE_BYTES]
   double* part;              // partial sums [segments][NE][n_slots]
   int64_t n_slots;
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
   constexpr int PIECES = SB / (16 * BLOCK_THREADS);
   constexpr float LOG2E = 1.4426950408889634f;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][SB];
-  __shared__ __attribute__((aligned(16))) float wsc[WAVES_PER_BLOCK][TT][2][NE][CELL_TILE];
+  __shared__ __attribute__((aligned(16))) float wsc[WAVES_PER_BLOCK][2][NE][CELL_TILE];
 
   int tb, seg;
   block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
@@ -95,8 +96,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
 
   float dl[TT][3], cT[TT][3], U[TT];
   bf16x8 xb[TT];
-  int wsrc[TT];     // tile whose W array this tile uses (first tile of its cell within the wave)
-  bool fresh[TT];   // this tile starts a new cell
+  bool live[TT];  // false: one of the empty tiles that pad a cell to a multiple of TT tiles (wave-uniform)
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(a.xd + ((tile0 + tt) * CELL_TILE + r) * 4);
@@ -124,14 +124,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
       const float lo_k = f[j], hi_k = f[8 + j];  // lane half 0: k = j, lane half 1: k = 8 + j
       xb[tt][j] = (__bf16)(h ? hi_k : lo_k);
     }
-    const int key = __builtin_amdgcn_readfirstlane(__float_as_int(m[3]));
-    int prev = 0;
-    if (tt > 0) {
-      const f32x4 mp = *reinterpret_cast<const f32x4*>(a.tmeta + (tile0 + tt - 1) * 4);
-      prev = __builtin_amdgcn_readfirstlane(__float_as_int(mp[3]));
-    }
-    fresh[tt] = (tt == 0) || (key != prev);
-    wsrc[tt] = fresh[tt] ? tt : wsrc[tt > 0 ? tt - 1 : 0];
+    live[tt] = ((__builtin_amdgcn_readfirstlane(__float_as_int(m[3])) >> 30) & 1) == 0;
     U[tt] = 0.f;
   }
 
@@ -174,17 +167,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
         const int qh = 2 * qp + h;
         const f32x4 hc = hdr[qh];
         const f32x4 mt = *reinterpret_cast<const f32x4*>(&lds[buf][qh * CELL_TILE_BYTES + CELL_A_BYTES + r * 16]);
+        float arg = 0.f;
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-          if (fresh[tt]) {  // wave-uniform
-            float arg = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) arg = fmaf(mt[c], 2.f * (cT[tt][c] - hc[c]) - mt[c], arg);
-            const float w = kexp2(arg * LOG2E);
-            wsc[wave][tt][h][0][r] = w * mt[3];
-            if constexpr (SIG == SIG_NORM) wsc[wave][tt][h][1][r] = w;
-          }
-        }
+        for (int c = 0; c < 3; ++c) arg = fmaf(mt[c], 2.f * (cT[0][c] - hc[c]) - mt[c], arg);
+        const float w = kexp2(arg * LOG2E);
+        wsc[wave][h][0][r] = w * mt[3];
+        if constexpr (SIG == SIG_NORM) wsc[wave][h][1][r] = w;
         __builtin_amdgcn_wave_barrier();
       }
 #pragma unroll
@@ -206,28 +194,34 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
             U[tt] = kexp2(s2 * -LOG2E);
           }
         }
+        // W_j b_j of this source tile in the register layout (registers 4g..4g+3 = source rows
+        // 8g+4h .. 8g+4h+3): broadcast reads, shared by the wave's TT target tiles
+        const float* wp = &wsc[wave][hq][0][0];
+        f32x4 wv[4], wd[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          wv[g] = *reinterpret_cast<const f32x4*>(wp + 8 * g + 4 * h);
+          if constexpr (SIG == SIG_NORM) wd[g] = *reinterpret_cast<const f32x4*>(wp + CELL_TILE + 8 * g + 4 * h);
+        }
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
+          if (tt > 0 && !live[tt]) continue;  // wave-uniform
           f32x16 d;
 #pragma unroll
           for (int qq = 0; qq < 16; ++qq) d[qq] = 0.f;
           d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, xb[tt], d, 0, 0, 0);
-          // registers 4g..4g+3 hold source rows 8g+4h .. 8g+4h+3
-          const float* wp = &wsc[wave][wsrc[tt]][hq][0][0];
           float p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + 8 * g + 4 * h);
-            p0 = fmaf(d[4 * g + 0], wv[0], p0);
-            p1 = fmaf(d[4 * g + 1], wv[1], p1);
-            p0 = fmaf(d[4 * g + 2], wv[2], p0);
-            p1 = fmaf(d[4 * g + 3], wv[3], p1);
+            p0 = fmaf(d[4 * g + 0], wv[g][0], p0);
+            p1 = fmaf(d[4 * g + 1], wv[g][1], p1);
+            p0 = fmaf(d[4 * g + 2], wv[g][2], p0);
+            p1 = fmaf(d[4 * g + 3], wv[g][3], p1);
             if constexpr (SIG == SIG_NORM) {
-              const f32x4 wd = *reinterpret_cast<const f32x4*>(wp + CELL_TILE + 8 * g + 4 * h);
-              q0 = fmaf(d[4 * g + 0], wd[0], q0);
-              q1 = fmaf(d[4 * g + 1], wd[1], q1);
-              q0 = fmaf(d[4 * g + 2], wd[2], q0);
-              q1 = fmaf(d[4 * g + 3], wd[3], q1);
+              q0 = fmaf(d[4 * g + 0], wd[g][0], q0);
+              q1 = fmaf(d[4 * g + 1], wd[g][1], q1);
+              q0 = fmaf(d[4 * g + 2], wd[g][2], q0);
+              q1 = fmaf(d[4 * g + 3], wd[g][3], q1);
             }
           }
           acc[tt][0] = fmaf(U[tt], p0 + p1, acc[tt][0]);

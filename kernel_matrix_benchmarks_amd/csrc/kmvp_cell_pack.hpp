@@ -38,7 +38,9 @@ __global__ void __launch_bounds__(CELL_TILE) pack_cell_targets_kernel(
     d[a] = valid ? x[idx * D + a] - c[a] : 0.f;
   }
   *reinterpret_cast<f32x4*>(xd + (g * CELL_TILE + r) * 4) = f32x4{d[0], d[1], d[2], 0.f};
-  if (r == 0) *reinterpret_cast<f32x4*>(tmeta + g * 4) = f32x4{c[0], c[1], c[2], __builtin_bit_cast(float, key)};
+  const bool empty = g >= n_groups || gcnt[g] == 0;
+  if (r == 0)
+    *reinterpret_cast<f32x4*>(tmeta + g * 4) = f32x4{c[0], c[1], c[2], __builtin_bit_cast(float, key | (empty ? 1u << 30 : 0u))};
   if (valid) slot_of[idx] = (int)(g * CELL_TILE + r);
 }
 

@@ -636,10 +636,10 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
 
 // ---- cell-reduced Gaussian path (kmvp_cell.hpp): float32, D <= 3, E == 1 -----------------------------
 
-// Cell order of one cloud: keys -> radix sort -> tiles of <= 32 points that never straddle a cell.
-// The tile list is built on the host from the sorted keys (one pass over n keys, once per kmvp_set_points).
-int cell_order(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, kmvp_ctx::DevBuf& perm,
-               kmvp_ctx::DevBuf& grp, int64_t* n_tiles) {
+// Cell order of one cloud: keys -> radix sort; the sorted keys come back to the host, where the
+// tile lists are built (one pass over n keys, once per kmvp_set_points).
+int cell_sort(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, kmvp_ctx::DevBuf& perm,
+              std::vector<unsigned>& keys) {
   int rc;
   const int D = c->D;
   size_t tmp_bytes = 0;
@@ -654,9 +654,17 @@ int cell_order(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, k
   hipLaunchKernelGGL(cell_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, pts, n, D, grid, keys_in, vals_in);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sort_pairs_u32(tmp, &tmp_bytes, keys_in, keys_out, vals_in, (int*)perm.p, n, c->stream));
-  std::vector<unsigned> keys((size_t)n);
+  keys.resize((size_t)n);
   HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_out, keys_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return KMVP_OK;
+}
+
+// Tiles of <= 32 points that never straddle a cell; every cell gets a multiple of `mult` tiles (the
+// extra ones are empty), so that the `mult` target tiles of a wavefront always share their cell.
+// Device layout of the list: [start][count][key], n_tiles entries each.
+int cell_tiles(kmvp_ctx* c, const std::vector<unsigned>& keys, int mult, kmvp_ctx::DevBuf& grp, int64_t* n_tiles) {
+  const int64_t n = (int64_t)keys.size();
   std::vector<int> start, count;
   std::vector<unsigned> gkey;
   start.reserve((size_t)n / 24 + 16);
@@ -665,14 +673,21 @@ int cell_order(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, k
   for (int64_t p = 0; p < n;) {
     int64_t e = p + 1;
     while (e < n && keys[(size_t)e] == keys[(size_t)p]) ++e;
-    for (int64_t t = p; t < e; t += CELL_TILE) {
+    int tiles = 0;
+    for (int64_t t = p; t < e; t += CELL_TILE, ++tiles) {
       start.push_back((int)t);
       count.push_back((int)std::min<int64_t>(CELL_TILE, e - t));
+      gkey.push_back(keys[(size_t)p]);
+    }
+    for (; tiles % mult; ++tiles) {
+      start.push_back((int)p);
+      count.push_back(0);
       gkey.push_back(keys[(size_t)p]);
     }
     p = e;
   }
   const size_t G = start.size();
+  int rc;
   if ((rc = ensure(c, grp, 3 * G * sizeof(int)))) return rc;
   HIP_TRY(c, hipMemcpyAsync(grp.p, start.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync((int*)grp.p + G, count.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -685,8 +700,8 @@ int cell_order(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, k
 // Grid and cell order of both clouds for the current points (cached per points version).
 // Leaves c->cell_state = 1 when the path can run, -1 when it cannot (D > 3, non-finite box, more
 // than 1024 cells along an axis).
-int cell_prepare(kmvp_ctx* c) {
-  if (c->cell_ver == c->points_ver && c->cell_state != 0) return KMVP_OK;
+int cell_prepare(kmvp_ctx* c, int TT) {
+  if (c->cell_ver == c->points_ver && c->cell_state != 0 && (c->cell_state < 0 || c->cell_tt == TT)) return KMVP_OK;
   c->cell_ver = c->points_ver;
   c->cell_state = -1;
   const int D = c->D;
@@ -709,12 +724,12 @@ int cell_prepare(kmvp_ctx* c) {
     grid.g[a] = (int)cells;
   }
   int rc;
-  if ((rc = cell_order(c, (const float*)c->y_raw.p, c->M, grid, c->cell_sperm, c->cell_sgrp, &c->cell_m_tiles))) return rc;
-  if (c->same_points) {
-    c->cell_n_tiles = c->cell_m_tiles;
-  } else {
-    if ((rc = cell_order(c, (const float*)c->x_raw.p, c->N, grid, c->cell_tperm, c->cell_tgrp, &c->cell_n_tiles))) return rc;
-  }
+  std::vector<unsigned> keys;
+  if ((rc = cell_sort(c, (const float*)c->y_raw.p, c->M, grid, c->cell_sperm, keys))) return rc;
+  if ((rc = cell_tiles(c, keys, 1, c->cell_sgrp, &c->cell_m_tiles))) return rc;
+  if (!c->same_points && (rc = cell_sort(c, (const float*)c->x_raw.p, c->N, grid, c->cell_tperm, keys))) return rc;
+  if ((rc = cell_tiles(c, keys, TT, c->cell_tgrp, &c->cell_n_tiles))) return rc;
+  c->cell_tt = TT;
   for (int a = 0; a < 3; ++a) {
     c->cell_lo[a] = grid.lo[a];
     c->cell_g[a] = grid.g[a];
@@ -726,7 +741,7 @@ int cell_prepare(kmvp_ctx* c) {
 }
 
 // share of slots over points after padding the last tile of every cell (both clouds)
-double cell_padding(const kmvp_ctx* c) {
+double cell_padding(const kmvp_ctx* c) {  // (empty tiles included)
   const double t = (double)c->cell_n_tiles * CELL_TILE / (double)std::max<int64_t>(c->N, 1);
   const double s = (double)c->cell_m_tiles * CELL_TILE / (double)std::max<int64_t>(c->M, 1);
   return std::max(t, s);
@@ -738,9 +753,8 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   const int NE = sig == SIG_NORM ? 2 : 1;
   const int64_t N = c->N;
   const bool small = N < SMALL_PROBLEM_TARGETS;
-  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (small ? 1 : CELL_DEFAULT_TT);
-  const int64_t tiles_per_block_max = 4 * WAVES_PER_BLOCK;  // TT <= 4: the padded tile count suits every TT
-  const int64_t n_tiles = round_up(c->cell_n_tiles, tiles_per_block_max);
+  const int TT = c->cell_tt;  // the target tile list was built for it (cell_prepare)
+  const int64_t n_tiles = round_up(c->cell_n_tiles, (int64_t)TT * WAVES_PER_BLOCK);
   const int64_t n_slots = n_tiles * CELL_TILE;
   const int64_t tile_blocks = n_tiles / (TT * WAVES_PER_BLOCK);
   const int64_t m_stages = (c->cell_m_tiles + CELL_STAGE_TILES - 1) / CELL_STAGE_TILES;
@@ -758,11 +772,11 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
 
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
-                         c->packed_layout != LAYOUT_CELL;
+                         c->packed_layout != LAYOUT_CELL || c->packed_T != TT;
   const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   const int* tperm = (const int*)(c->same_points ? c->cell_sperm.p : c->cell_tperm.p);
-  const int* tgrp = (const int*)(c->same_points ? c->cell_sgrp.p : c->cell_tgrp.p);
+  const int* tgrp = (const int*)c->cell_tgrp.p;
   const int* sgrp = (const int*)c->cell_sgrp.p;
   if (pts_stale) {
     if ((rc = ensure(c, c->xs, (size_t)n_slots * 4 * sizeof(float)))) return rc;
@@ -1001,7 +1015,8 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     // (Gaussian, D <= 3).  auto: when the clouds fill the cells well enough that padding stays small.
     if (kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->async_product &&
         (c->opt_fast == 3 || (c->opt_fast < 0 && global_ok && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
-      int rc = cell_prepare(c);
+      const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, 4) : (c->N < SMALL_PROBLEM_TARGETS ? 1 : CELL_DEFAULT_TT);
+      int rc = cell_prepare(c, TT == 3 ? 2 : TT);
       if (rc) return rc;
       if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) return run_product_cell(c, sig);
     }
