@@ -47,7 +47,13 @@ SLOTS_PER_PAIR = {
     "fast_kernel": {"gaussian": 5, "inverse-distance": 5, "absolute-exponential": 9},
     # centred form: + ~0.7 per pair for the operand rebuild and the reach flag
     "cfast_kernel": {"gaussian": 5.7, "inverse-distance": 5.7, "absolute-exponential": 9.7},
+    # cell form: the exponential is range-reduced by grid cells and its remainder polynomial comes out of
+    # the matrix pipe; per pair the VALU owes ONE fma (the per-cell exponentials amortise to < 0.1 slot)
+    "cell_kernel": {"gaussian": 1.0},
 }
+# VALU flops per pair the cell form needs by construction (one fma); its matrix-pipe flops per pair
+CELL_VALU_FLOPS_PER_PAIR = 2
+MFMA_FLOPS_PER_PAIR_CELL = 2 * 16  # one 32x32x16 bf16 MFMA per 1024 pairs
 MFMA_FLOPS_PER_PAIR_FAST = 2 * 32  # two 32x32x16 bf16 k-steps (K = 6 D + 6 = 24 -> 32) for D = 3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 
@@ -60,7 +66,7 @@ def parse():
     p.add_argument("--points", dest="n", type=float, default=1e6, help="points (N = M); default = BASELINE config 2")
     p.add_argument("--kernel", choices=sorted(KERNELS), default="gaussian")
     p.add_argument("--precision", choices=["float32", "float64"], default="float32")
-    p.add_argument("--sqdists", choices=["auto", "difference", "expanded"], default="auto",
+    p.add_argument("--sqdists", choices=["auto", "difference", "expanded", "cells"], default="auto",
                    help="squared-distance form (the reference's fast_sqdists flag): auto = expanded form on "
                         "the matrix cores where it is as accurate as the difference form")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,7 +145,7 @@ def main():
     y = rs.rand(n, D)
     b = rs.randn(n, E)
 
-    fast = {"auto": None, "difference": False, "expanded": True}[args.sqdists]
+    fast = {"auto": None, "difference": False, "expanded": True, "cells": "cells"}[args.sqdists]
     device = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
     algo = MI355XProduct(kernel=kernel, dimension=D, precision=args.precision, device=device, comm=comm,
                          fast_sqdists=fast)
@@ -166,15 +172,21 @@ def main():
     kname = algo.device_kernel
     # the other squared-distance form on the same resident data, for the record (3 steps, untimed region)
     other = None
-    if args.sqdists == "auto" and kname in ("fast_kernel", "cfast_kernel") and world == 1:
-        algo.set_query_arguments(fast_sqdists=0)
-        algo.query()
-        oms = []
-        for _ in range(3):
+    expanded = None
+    if args.sqdists == "auto" and kname in ("fast_kernel", "cfast_kernel", "cell_kernel") and world == 1:
+        def side_run(code):
+            algo.set_query_arguments(fast_sqdists=code)
             algo.query()
-            oms.append(algo.device_kernel_ms)
-        other = {"kernel": algo.device_kernel, "kernel_ms": float(np.mean(oms)),
-                 "pairs_per_s": float(n) * float(n) / (float(np.mean(oms)) * 1e-3)}
+            oms = []
+            for _ in range(3):
+                algo.query()
+                oms.append(algo.device_kernel_ms)
+            return {"kernel": algo.device_kernel, "kernel_ms": float(np.mean(oms)),
+                    "pairs_per_s": float(n) * float(n) / (float(np.mean(oms)) * 1e-3)}
+
+        other = side_run(0)
+        if kname == "cell_kernel":
+            expanded = side_run(1)  # fast_kernel: one v_exp_f32 per pair, squared distance on the matrix cores
         algo.set_query_arguments(fast_sqdists=-1)
     max_err = rel_err = None
     if rank == 0:
@@ -192,7 +204,12 @@ def main():
         sec_per_step = elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
         shard_pairs = float(n) * float(algo.shard[1] - algo.shard[0])
-        flops = FLOPS_PER_PAIR[kernel] * shard_pairs
+        # roofline.achieved counts the flops the bounding unit (VALU) has to execute for this algorithm:
+        # SURVEY 8d's 3D + 2E + 1 = 12 per pair for the kernels that evaluate exp() per pair on the VALU;
+        # the cell form leaves one fma (2 flops) per pair there -- the rest runs on the matrix pipe, so
+        # the 12-flop count is reported beside it as an equivalent, not as a fraction of the vector peak
+        flops_per_pair = CELL_VALU_FLOPS_PER_PAIR if kname == "cell_kernel" else FLOPS_PER_PAIR[kernel]
+        flops = flops_per_pair * shard_pairs
         achieved_tflops = flops / (k_ms * 1e-3) / 1e12
         traffic = None
         # HBM-side bytes per launch of this exact workload, measured with rocprofv3 PMC passes
@@ -234,13 +251,15 @@ def main():
                 "traffic": traffic,
                 "kernel_ms": k_ms,
                 "step_device_ms": total_ms,
-                "flops_per_pair": FLOPS_PER_PAIR[kernel],
+                "flops_per_pair": flops_per_pair,
+                "survey_equivalent_tflops": FLOPS_PER_PAIR[kernel] * shard_pairs / (k_ms * 1e-3) / 1e12,
                 # the same launch priced in VALU issue slots (transcendental = 4 slots)
                 "issue_slots_per_pair": SLOTS_PER_PAIR.get(kname, SLOTS_PER_PAIR["lowd_kernel"])[kernel],
                 "issue_frac": SLOTS_PER_PAIR.get(kname, SLOTS_PER_PAIR["lowd_kernel"])[kernel] * shard_pairs
                               / (k_ms * 1e-3) / PEAK_ISSUE_SLOTS,
-                "mfma_frac": (MFMA_FLOPS_PER_PAIR_FAST * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
-                              if kname in ("fast_kernel", "cfast_kernel") else 0.0),
+                "mfma_frac": ((MFMA_FLOPS_PER_PAIR_CELL if kname == "cell_kernel" else MFMA_FLOPS_PER_PAIR_FAST)
+                              * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
+                              if kname in ("fast_kernel", "cfast_kernel", "cell_kernel") else 0.0),
                 # north-star's "HBM" reading: bytes every wavefront streams from the source block
                 "source_stream_GBps": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4 / (k_ms * 1e-3) / 1e9,
                 "source_stream_frac_of_hbm_peak": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4
@@ -248,13 +267,18 @@ def main():
                 "algorithmic_hbm_bytes": 4 * (n * D + (algo.shard[1] - algo.shard[0]) * (D + E) + n * E),
             },
         }
-        out["config"]["sqdists"] = ("expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "
+        out["config"]["sqdists"] = ("cells: exp() range-reduced by grid cells, remainder polynomial of 2 d.e on the bf16 "
+                                    "matrix cores (one 32x32x16 MFMA per 1024 pairs), one fma per pair on the VALU"
+                                    if kname == "cell_kernel" else
+                                    "expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "
                                     "(reference fast_sqdists=True form)" if kname == "fast_kernel"
                                     else "expanded around per-group centres of Morton-sorted sources on the bf16 matrix "
                                          "cores, closest pairs recomputed exactly" if kname == "cfast_kernel"
                                     else "difference form (reference fast_sqdists=False)")
         if other is not None:
             out["difference_form"] = other
+        if expanded is not None:
+            out["expanded_form"] = expanded
         if not args.no_cpu_baseline and args.gpus == 1:
             out["cpu_baseline"] = cpu_baseline(kernel, y, b, args.precision, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -270,6 +270,16 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     LowdTuning tune;
     tune.feed = c->opt_feed >= 0 ? c->opt_feed : DEFAULT_FEED;
     tune.targets_per_lane = c->opt_T > 0 ? c->opt_T : (tune.feed == 1 ? DEFAULT_TARGETS_PER_LANE : 2);
+    if (!(D == 3 && E == 1)) {
+      // only the headline shape carries the whole (T, feed) grid; elsewhere a requested T keeps its
+      // instantiated feed (T = 1: LDS tiles, T = 2: scalar-cache stream), anything else is the default
+      if (tune.targets_per_lane == 2 && c->opt_T > 0) tune.feed = 0;
+      else if (tune.feed == 0 && c->opt_T <= 0) tune.targets_per_lane = 2;
+      else {
+        tune.targets_per_lane = DEFAULT_TARGETS_PER_LANE;
+        tune.feed = DEFAULT_FEED;
+      }
+    }
     const int T = tune.targets_per_lane;
     const int EB = sig == SIG_DENSITY ? 0 : E;
     const int R = (D + EB + 3) / 4 * 4;
