@@ -95,17 +95,14 @@ __global__ void __launch_bounds__(CELL_TILE) pack_cell_sources_kernel(
         f32x4{c[0], c[1], c[2], __builtin_bit_cast(float, real_tile ? (int)key : -1)};
 }
 
-// sums[e][i] = sum over segments (index order) of part[s][e][slot_of[i]]: segment reduction and the
-// way back from cell order to the caller's order in one pass
-__global__ void reduce_cells_kernel(const double* __restrict__ part, const int* __restrict__ slot_of,
-                                    double* __restrict__ sums, int64_t n, int64_t n_slots, int NE, int segments) {
+// sums[e][i] = sorted[e][slot_of[i]]: the way back from cell order to the caller's order (the segments
+// were summed in cell order first, coalesced)
+__global__ void gather_cells_kernel(const double* __restrict__ sorted, const int* __restrict__ slot_of,
+                                    double* __restrict__ sums, int64_t n, int64_t n_slots, int NE) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= (int64_t)NE * n) return;
   const int64_t e = q / n, i = q % n;
-  const int64_t at = e * n_slots + slot_of[i];
-  double v = 0.0;
-  for (int s = 0; s < segments; ++s) v += part[(int64_t)s * NE * n_slots + at];
-  sums[q] = v;
+  sums[q] = sorted[e * n_slots + slot_of[i]];
 }
 
 }  // namespace kmvp

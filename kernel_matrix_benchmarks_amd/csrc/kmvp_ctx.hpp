@@ -108,8 +108,9 @@ struct kmvp_ctx {
   DevBuf sortbuf, perm;         // centred path: radix-sort scratch, Morton order of the sources
   DevBuf x_scaled, y_scaled;    // scaled copies (generic path)
   // cell-reduced Gaussian path (kmvp_cell.hpp): cell order of targets / sources, their tiles
-  // ([start][count][key] per tile), slot of every target in cell order, target tile centres
-  DevBuf cell_tperm, cell_sperm, cell_tgrp, cell_sgrp, cell_slot, cell_tmeta;
+  // ([start][count][key] per tile), slot of every target in cell order, target tile centres,
+  // segment-reduced sums in cell order
+  DevBuf cell_tperm, cell_sperm, cell_tgrp, cell_sgrp, cell_slot, cell_tmeta, cell_sums;
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
   DevBuf xchg;                  // sharded runs: sums in the canonical unpadded layout [column][N] for the all-reduce
   DevBuf scratch;               // CG vectors / dot products

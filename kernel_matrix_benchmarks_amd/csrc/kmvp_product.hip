@@ -557,7 +557,7 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   const int EB = sig == SIG_DENSITY ? 0 : 1;
   const int64_t N = c->N, M = c->M;
   const bool small = N < SMALL_PROBLEM_TARGETS;  // see run_product_fast
-  const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (small ? 1 : CFAST_DEFAULT_TT);
+  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, 4) : (small ? 1 : CFAST_DEFAULT_TT);
   const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   const int64_t tile = (int64_t)32 * TT * WAVES_PER_BLOCK;
@@ -834,8 +834,11 @@ int run_product_cell(kmvp_ctx* c, int sig) {
 
   // ---- epilogue: segments -> sums in the caller's order, [all-reduce over the source shards], normalise
   if ((rc = ensure(c, c->sums, (size_t)NE * N * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_cells_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, NE, segments);
+  if ((rc = ensure(c, c->cell_sums, (size_t)NE * n_slots * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for((int64_t)NE * n_slots)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->cell_sums.p, (int64_t)NE * n_slots, segments);
+  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream,
+                     (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, NE);
   HIP_TRY(c, hipGetLastError());
   return finish_product(c, (int64_t)NE * N, N, N, E, sig);
 }
@@ -1025,8 +1028,8 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     // (Gaussian, D <= 3).  auto: when the clouds fill the cells well enough that padding stays small.
     if (kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->async_product &&
         (c->opt_fast == 3 || (c->opt_fast < 0 && global_ok && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
-      const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, 4) : (c->N < SMALL_PROBLEM_TARGETS ? 1 : CELL_DEFAULT_TT);
-      int rc = cell_prepare(c, TT == 3 ? 2 : TT);
+      const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : CELL_DEFAULT_TT);
+      int rc = cell_prepare(c, TT);
       if (rc) return rc;
       if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) return run_product_cell(c, sig);
     }

@@ -501,11 +501,12 @@ def test_single_rank_rccl_communicator():
     """kmvp_comm_get_unique_id / kmvp_comm_init / ncclAllReduce with world == 1 on the one GPU.
     With a communicator attached every path goes through the exchange in the canonical unpadded
     layout [column][N] (ranks may pick kernels with different tile padding): lowd / fast / cfast /
-    mfma kernels, N not a multiple of any tile size."""
+    cell / mfma kernels, N not a multiple of any tile size."""
     n = 1000 + 37
     y, b = kmvp_oracle.uniform_cube(n, 3)
     cases = [("gaussian", True, _lib.KMVP_F32, 0, "lowd_kernel"), ("gaussian", True, _lib.KMVP_F32, 1, "fast_kernel"),
              ("inverse-distance", False, _lib.KMVP_F32, 2, "cfast_kernel"),
+             ("gaussian", False, _lib.KMVP_F32, 3, "cell_kernel"), ("gaussian", True, _lib.KMVP_F32, 3, "cell_kernel"),
              ("absolute-exponential", True, _lib.KMVP_F64, 0, "lowd_kernel")]
     for kernel, norm, dtype, fast, kname in cases:
         npdt = np.float64 if dtype == _lib.KMVP_F64 else np.float32
