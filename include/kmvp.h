@@ -139,10 +139,15 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  *                      1 = always, around one centre for the whole cloud (fast_kernel);
  *                      2 = always, around per-group centres of Morton-sorted sources with exact
  *                          recomputation of the closest pairs (cfast_kernel, D <= 4);
+ *                      3 = always the cell form (cell_kernel: Gaussian, D <= 3): exp() is range-reduced
+ *                          by the cells of a regular grid, exp(-|x-y|^2) = U_i(S) W_j(T) exp(2 d.e),
+ *                          and the remainder polynomial 1 + t + t^2/2 of t = 2 d.e (|t| <= 0.006)
+ *                          comes out of one bf16 MFMA per 32 x 32 pairs;
  *                      0 = never (difference form, bruteforce.py:53-54);
  *                      -1 = auto (default): the cheapest form that is as accurate as the
- *                          difference form -- 1 for the Gaussian on clouds of small scaled
- *                          radius, else 2 where it applies
+ *                          difference form -- for the Gaussian on clouds of small scaled radius
+ *                          3 when both clouds fill the grid cells (>= 32768 points, padding
+ *                          <= 30 %), else 1; else 2 where it applies
  *   "same_points_global" 1 when the targets passed to kmvp_set_points are the unsharded
  *                      sources (sharded same_points): enables form 2 for inverse-distance
  *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4
