@@ -91,6 +91,14 @@ class MI355XProduct(BaseProduct):
             # every rank keeps all targets and one contiguous slice of the sources
             self._shard = sharding.shard_range(self.M, self.comm.rank, world)
             lo, hi = self._shard
+            # Gaussian (no index-based rule): shard the sources cell by cell instead of in the caller's
+            # order -- every rank derives the same permutation from the full cloud it was handed
+            self._order = (sharding.spatial_order(y) if self.kernel == "gaussian" and self._host_dtype == np.float32
+                           else None)
+            if self._order is not None:
+                targets = y if x is None else x
+                y = y[self._order]
+                x = targets
             self.comm.attach(self._ctx)
             # the context sees the targets as an explicit array; tell it when they ARE the
             # (unsharded) sources, which the inverse-distance zero rule of the centred form needs
@@ -99,6 +107,7 @@ class MI355XProduct(BaseProduct):
                                  self._dtype_code, j_offset=lo, M_total=self.M)
         else:
             self._shard = (0, self.M)
+            self._order = None
             self._ctx.set_points(y, x, self._dtype_code)
 
     def prepare_query(self, *, source_signal):
@@ -111,6 +120,8 @@ class MI355XProduct(BaseProduct):
             b = b.reshape(-1, 1)
         self.E = b.shape[1]
         lo, hi = self._shard
+        if self._order is not None:
+            b = b[self._order]  # the sources were sharded in cell order (prepare_data)
         self._ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
 
     def get_result(self):
@@ -210,6 +221,14 @@ class MI355XSolver(BaseSolver):
             # is sharded over the sources and summed by the product's own all-reduce
             self._shard = sharding.shard_range(self.M, self.comm.rank, world)
             lo, hi = self._shard
+            # Gaussian (no index-based rule): shard the sources cell by cell instead of in the caller's
+            # order -- every rank derives the same permutation from the full cloud it was handed
+            self._order = (sharding.spatial_order(y) if self.kernel == "gaussian" and self._host_dtype == np.float32
+                           else None)
+            if self._order is not None:
+                targets = y if x is None else x
+                y = y[self._order]
+                x = targets
             self.comm.attach(self._ctx)
             self._ctx.set_option("same_points_global", 1)
             self._ctx.set_points(np.ascontiguousarray(y[lo:hi]), y, self._dtype_code, j_offset=lo, M_total=self.M)

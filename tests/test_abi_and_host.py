@@ -128,6 +128,35 @@ def test_shard_ranges_partition_the_sources():
         sharding.shard_range(10, 2, 2)
 
 
+def test_spatial_order_keeps_cells_together_and_sums_unchanged():
+    """Sharded Gaussian products hand rank r the r-th slice of the sources in cell order
+    (sharding.spatial_order): a permutation, each slice confined to its share of the cells, the
+    signal permuted the same way -- the shard sums still add up to the unsharded product."""
+    rs = np.random.RandomState(8)
+    y = rs.rand(4000, 3)
+    b = rs.randn(4000, 1)
+    order = sharding.spatial_order(y)
+    assert sorted(order.tolist()) == list(range(4000))
+    h = np.sqrt(2 * 0.006 / 3)
+    cells = np.floor((y.astype(np.float32) - y.astype(np.float32).min(axis=0)) / np.float32(h)).astype(int)
+    keys = cells[:, 0] + 1024 * cells[:, 1] + 1024 * 1024 * cells[:, 2]
+    assert (np.diff(keys[order]) >= 0).all()
+    world = 4
+    total = np.zeros((50, 1))
+    distinct = 0
+    for rank in range(world):
+        lo, hi = sharding.shard_range(4000, rank, world)
+        idx = order[lo:hi]
+        distinct += len(np.unique(keys[idx]))
+        total += kmvp_oracle.product(kernel="gaussian", source_points=y[idx], target_points=y[:50], source_signal=b[idx])
+    assert distinct <= len(np.unique(keys)) + world - 1  # a cell is split over at most two neighbouring ranks
+    full = kmvp_oracle.product(kernel="gaussian", source_points=y, target_points=y[:50], source_signal=b)
+    np.testing.assert_allclose(total, full, rtol=1e-12, atol=1e-12)
+    assert sharding.spatial_order(rs.rand(10, 4)) is None                  # D > 3: no cell grid
+    assert sharding.spatial_order(np.array([[0.0, 0, 0], [np.inf, 0, 0]])) is None
+    assert sharding.spatial_order(np.array([[0.0, 0, 0], [100.0, 0, 0]])) is None  # > 1024 cells along an axis
+
+
 def test_container_roundtrip(tmp_path):
     fn = str(tmp_path / ("roundtrip" + storage.extension()))
     a = np.arange(12.0).reshape(4, 3)

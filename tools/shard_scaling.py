@@ -6,19 +6,23 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from kernel_matrix_benchmarks_amd import _lib
+from kernel_matrix_benchmarks_amd import _lib, sharding
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 kernel = sys.argv[2] if len(sys.argv) > 2 else "gaussian"
 rs = np.random.RandomState(n + 3)
 y = rs.rand(n, 3).astype(np.float32); b = rs.randn(n, 1).astype(np.float32)
+# argv[3] = "caller": shard in the caller's order even where the plugin would shard cell by cell (Gaussian)
+order = sharding.spatial_order(y) if kernel == "gaussian" and (len(sys.argv) <= 3 or sys.argv[3] != "caller") else None
+ys, bs = (y, b) if order is None else (y[order], b[order])
+print("sources sharded", "in the caller's order" if order is None else "cell by cell (sharding.spatial_order)")
 base = None
 for world in (1, 2, 4, 8):
     lo, hi = 0, (n + world - 1) // world
     ctx = _lib.Context(0)
     ctx.set_option("same_points_global", 1)
-    ctx.set_points(np.ascontiguousarray(y[lo:hi]), y, _lib.KMVP_F32, j_offset=lo, M_total=n)
-    ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
+    ctx.set_points(np.ascontiguousarray(ys[lo:hi]), y, _lib.KMVP_F32, j_offset=lo, M_total=n)
+    ctx.set_signal(np.ascontiguousarray(bs[lo:hi]))
     ctx.run(kernel, False); ctx.run(kernel, False)
     wall, kms, tms = [], [], []
     for _ in range(10):
