@@ -157,6 +157,48 @@ def test_spatial_order_keeps_cells_together_and_sums_unchanged():
     assert sharding.spatial_order(np.array([[0.0, 0, 0], [100.0, 0, 0]])) is None  # > 1024 cells along an axis
 
 
+def test_plugin_shards_gaussian_sources_cell_by_cell(monkeypatch):
+    """MI355XProduct with a 2-rank communicator (device context replaced by a recorder): the Gaussian
+    hands the library its slice of the sources in cell order with the signal permuted alike; the
+    inverse-distance kernel keeps the caller's order (index-based zero rule)."""
+    calls = {}
+
+    class Recorder:
+        def __init__(self, device=0):
+            pass
+
+        def set_option(self, key, value):
+            calls.setdefault("options", {})[key] = value
+
+        def set_points(self, y, x, dtype, j_offset=0, M_total=None):
+            calls["points"] = (y.copy(), None if x is None else x.copy(), j_offset, M_total)
+
+        def set_signal(self, b):
+            calls["signal"] = None if b is None else b.copy()
+
+    class FakeComm:
+        rank, world = 1, 2
+
+        def attach(self, ctx):
+            calls["attached"] = True
+
+    monkeypatch.setattr(_lib, "Context", Recorder)
+    rs = np.random.RandomState(3)
+    y = rs.rand(999, 3)
+    b = rs.randn(999, 1)
+    lo, hi = sharding.shard_range(999, 1, 2)
+    for kernel in ("gaussian", "inverse-distance"):
+        algo = mi355x.MI355XProduct(kernel=kernel, dimension=3, normalize_rows=False, precision="float32", comm=FakeComm())
+        algo.prepare_data(source_points=y, target_points=y, same_points=True)
+        algo.prepare_query(source_signal=b)
+        ys, xs, j_offset, m_total = calls["points"]
+        order = sharding.spatial_order(y.astype(np.float32)) if kernel == "gaussian" else np.arange(999)
+        assert calls["attached"] and (j_offset, m_total) == (lo, 999)
+        assert np.array_equal(ys, y.astype(np.float32)[order][lo:hi])
+        assert np.array_equal(xs, y.astype(np.float32))  # all targets, caller's order
+        assert np.array_equal(calls["signal"], b.astype(np.float32)[order][lo:hi])
+
+
 def test_container_roundtrip(tmp_path):
     fn = str(tmp_path / ("roundtrip" + storage.extension()))
     a = np.arange(12.0).reshape(4, 3)
