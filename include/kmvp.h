@@ -150,8 +150,9 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  *                          <= 30 %), else 1; else 2 where it applies
  *   "same_points_global" 1 when the targets passed to kmvp_set_points are the unsharded
  *                      sources (sharded same_points): enables form 2 for inverse-distance
- *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4
- *                      (clamped to what is instantiated: 4 up to D = 7, 2 up to D = 23, 1 beyond) */
+ *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4, 8
+ *                      (clamped to what is instantiated: fast_kernel 4 up to D = 7, 2 up to D = 23,
+ *                      1 beyond; cfast_kernel 4; cell_kernel 8) */
 int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);
 
 /* BaseAlgorithm.get_memory_usage / get_additional (base.py:35-46): bytes of device

@@ -238,8 +238,8 @@ int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
   } else if (k == "same_points_global") {
     c->opt_same_global = value != 0;
   } else if (k == "fast_tiles") {
-    if (value != 0 && value != 1 && value != 2 && value != 4)
-      return fail(c, KMVP_E_INVALID, "fast_tiles must be 0 (auto), 1, 2 or 4");
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+      return fail(c, KMVP_E_INVALID, "fast_tiles must be 0 (auto), 1, 2, 4 or 8");
     c->opt_fast_tiles = (int)value;
   } else if (k == "chunk") {
     if (value < 8 || value > (1 << 24)) return fail(c, KMVP_E_INVALID, "chunk out of range");

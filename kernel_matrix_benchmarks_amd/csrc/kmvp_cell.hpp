@@ -94,7 +94,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
   const int h = lane >> 5;
   const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
 
-  float dl[TT][3], cT[TT][3], U[TT];
+  // TT = 8 re-reads the targets' offsets when U is recomputed (every ~8 source tiles) instead of
+  // holding them: 24 registers decide between three and four waves per SIMD there
+  constexpr bool HOLD_D = TT < 8;
+  float dl[HOLD_D ? TT : 1][3], cT[3], U[TT];
   bf16x8 xb[TT];
   bool live[TT];  // false: one of the empty tiles that pad a cell to a multiple of TT tiles (wave-uniform)
 #pragma unroll
@@ -105,8 +108,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
     f[0] = 1.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      dl[tt][c] = v[c];
-      cT[tt][c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[c])));
+      if constexpr (HOLD_D) dl[tt][c] = v[c];
+      if (tt == 0) cT[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[c])));  // one cell per wave
       const float dh = (float)(__bf16)v[c];
       const float dm = (float)(__bf16)(v[c] - dh);
       f[1 + 3 * c] = dh;
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
         const f32x4 mt = *reinterpret_cast<const f32x4*>(&lds[buf][qh * CELL_TILE_BYTES + CELL_A_BYTES + r * 16]);
         float arg = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) arg = fmaf(mt[c], 2.f * (cT[0][c] - hc[c]) - mt[c], arg);
+        for (int c = 0; c < 3; ++c) arg = fmaf(mt[c], 2.f * (cT[c] - hc[c]) - mt[c], arg);
         const float w = kexp2(arg * LOG2E);
         wsc[wave][h][0][r] = w * mt[3];
         if constexpr (SIG == SIG_NORM) wsc[wave][h][1][r] = w;
@@ -185,10 +188,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
           key_s = ks;
 #pragma unroll
           for (int tt = 0; tt < TT; ++tt) {
+            f32x4 dv;
+            if constexpr (!HOLD_D) dv = *reinterpret_cast<const f32x4*>(a.xd + ((tile0 + tt) * CELL_TILE + r) * 4);
             float s2 = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              const float df = dl[tt][c] + (cT[tt][c] - cs[c]);
+              float df;
+              if constexpr (HOLD_D) df = dl[tt][c] + (cT[c] - cs[c]);
+              else df = dv[c] + (cT[c] - cs[c]);
               s2 = fmaf(df, df, s2);
             }
             U[tt] = kexp2(s2 * -LOG2E);

@@ -10,6 +10,7 @@ static hipError_t launch_tt(int TT, const CellArgs& args, dim3 grid, hipStream_t
     case 1: hipLaunchKernelGGL((cell_kernel<SIG, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
     case 2: hipLaunchKernelGGL((cell_kernel<SIG, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
     case 4: hipLaunchKernelGGL((cell_kernel<SIG, 4>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
+    case 8: hipLaunchKernelGGL((cell_kernel<SIG, 8>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
