@@ -50,7 +50,7 @@ constexpr int CELL_TILE_BYTES = CELL_A_BYTES + CELL_TILE * 16;     // + (e_x, e_
 constexpr int CELL_HDR_OFF = CELL_STAGE_TILES * CELL_TILE_BYTES;   // 4 x (c_x, c_y, c_z, cell key)
 constexpr int CELL_STAGE_BYTES = 8192;
 static_assert(CELL_HDR_OFF + CELL_STAGE_TILES * 16 <= CELL_STAGE_BYTES, "stage image too small");
-constexpr float CELL_T_MAX = 0.006f;  // bound on |2 d.e|: truncation t^3/6 <= 3.6e-8
+constexpr float CELL_T_MAX = 0.016f;  // bound on |2 d.e|: truncation t^3/6 <= 6.8e-7, typically 10x less
 constexpr int CELL_MAX_GRID = 1024;   // cells per axis (10 bits of the key each)
 
 struct CellGrid {

@@ -83,7 +83,6 @@ hipError_t launch_cfast_invdist(int sig, int TT, const CfastArgs& args, dim3 gri
                                 const char** kernel_name);
 // cell-reduced Gaussian path (kmvp_cell.hpp): float32, D <= 3, E == 1
 constexpr int CELL_MAX_D = 3;
-constexpr int CELL_DEFAULT_TT = 4;
 // auto mode: the path is taken when padding the cells' last tiles adds at most this share of slots
 constexpr double CELL_AUTO_MAX_PAD = 1.30;
 struct CellArgs;

@@ -707,11 +707,27 @@ int cell_tiles(kmvp_ctx* c, const std::vector<unsigned>& keys, int mult, kmvp_ct
   return KMVP_OK;
 }
 
+// tiles a cloud with these sorted cell keys occupies when every cell gets a multiple of `mult` tiles
+int64_t cell_count_tiles(const std::vector<unsigned>& keys, int mult) {
+  const int64_t n = (int64_t)keys.size();
+  int64_t tiles = 0;
+  for (int64_t p = 0; p < n;) {
+    int64_t e = p + 1;
+    while (e < n && keys[(size_t)e] == keys[(size_t)p]) ++e;
+    tiles += round_up((e - p + CELL_TILE - 1) / CELL_TILE, mult);
+    p = e;
+  }
+  return tiles;
+}
+
 // Grid and cell order of both clouds for the current points (cached per points version).
+// TT > 0: target tiles per wavefront as requested; TT == 0: the largest of 8, 4, 2 whose padding of the
+// target cells stays within CELL_AUTO_MAX_PAD (2 if none does).
 // Leaves c->cell_state = 1 when the path can run, -1 when it cannot (D > 3, non-finite box, more
 // than 1024 cells along an axis).
 int cell_prepare(kmvp_ctx* c, int TT) {
-  if (c->cell_ver == c->points_ver && c->cell_state != 0 && (c->cell_state < 0 || c->cell_tt == TT)) return KMVP_OK;
+  if (c->cell_ver == c->points_ver && c->cell_state != 0 && (c->cell_state < 0 || c->cell_tt_req == TT)) return KMVP_OK;
+  c->cell_tt_req = TT;
   c->cell_ver = c->points_ver;
   c->cell_state = -1;
   const int D = c->D;
@@ -738,6 +754,15 @@ int cell_prepare(kmvp_ctx* c, int TT) {
   if ((rc = cell_sort(c, (const float*)c->y_raw.p, c->M, grid, c->cell_sperm, keys))) return rc;
   if ((rc = cell_tiles(c, keys, 1, c->cell_sgrp, &c->cell_m_tiles))) return rc;
   if (!c->same_points && (rc = cell_sort(c, (const float*)c->x_raw.p, c->N, grid, c->cell_tperm, keys))) return rc;
+  if (TT == 0) {
+    TT = 2;
+    for (int t : {8, 4}) {
+      if ((double)cell_count_tiles(keys, t) * CELL_TILE <= CELL_AUTO_MAX_PAD * (double)c->N) {
+        TT = t;
+        break;
+      }
+    }
+  }
   if ((rc = cell_tiles(c, keys, TT, c->cell_tgrp, &c->cell_n_tiles))) return rc;
   c->cell_tt = TT;
   for (int a = 0; a < 3; ++a) {
@@ -1028,7 +1053,7 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     // (Gaussian, D <= 3).  auto: when the clouds fill the cells well enough that padding stays small.
     if (kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->async_product &&
         (c->opt_fast == 3 || (c->opt_fast < 0 && global_ok && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
-      const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : CELL_DEFAULT_TT);
+      const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : 0);  // 0: by the padding
       int rc = cell_prepare(c, TT);
       if (rc) return rc;
       if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) return run_product_cell(c, sig);

@@ -22,9 +22,12 @@ def shard_range(M, rank, world):
     return lo, hi
 
 
+CELL_T_MAX = 0.016  # kmvp_cell.hpp: bound on |2 d.e| that fixes the cell side
+
+
 def spatial_order(points):
     """Permutation that lists the points cell by cell of a regular grid (the grid of libkmvp's
-    ``cell_kernel``: side sqrt(2 * 0.006 / D)), or ``None`` when that grid does not apply (D > 3,
+    ``cell_kernel``: side sqrt(2 * CELL_T_MAX / D)), or ``None`` when that grid does not apply (D > 3,
     non-finite coordinates, more than 1024 cells along an axis).
 
     A sum over sources does not care about their order, so a sharded Gaussian product may hand rank r
@@ -38,7 +41,7 @@ def spatial_order(points):
     p = np.asarray(points, dtype=np.float32)
     if p.ndim != 2 or p.shape[0] == 0 or p.shape[1] > 3 or not np.isfinite(p).all():
         return None
-    h = np.float32(np.sqrt(2.0 * 0.006 / p.shape[1]))
+    h = np.float32(np.sqrt(2.0 * CELL_T_MAX / p.shape[1]))
     cells = np.floor((p - p.min(axis=0)) / h).astype(np.int64)
     if cells.max() >= 1024:
         return None

@@ -135,9 +135,11 @@ def test_spatial_order_keeps_cells_together_and_sums_unchanged():
     rs = np.random.RandomState(8)
     y = rs.rand(4000, 3)
     b = rs.randn(4000, 1)
+    header = open(os.path.join(os.path.dirname(__file__), "..", "kernel_matrix_benchmarks_amd", "csrc", "kmvp_cell.hpp")).read()
+    assert float(re.search(r"CELL_T_MAX = ([0-9.]+)f", header).group(1)) == sharding.CELL_T_MAX  # one grid on both sides
     order = sharding.spatial_order(y)
     assert sorted(order.tolist()) == list(range(4000))
-    h = np.sqrt(2 * 0.006 / 3)
+    h = np.sqrt(2 * sharding.CELL_T_MAX / 3)
     cells = np.floor((y.astype(np.float32) - y.astype(np.float32).min(axis=0)) / np.float32(h)).astype(int)
     keys = cells[:, 0] + 1024 * cells[:, 1] + 1024 * 1024 * cells[:, 2]
     assert (np.diff(keys[order]) >= 0).all()
@@ -154,7 +156,7 @@ def test_spatial_order_keeps_cells_together_and_sums_unchanged():
     np.testing.assert_allclose(total, full, rtol=1e-12, atol=1e-12)
     assert sharding.spatial_order(rs.rand(10, 4)) is None                  # D > 3: no cell grid
     assert sharding.spatial_order(np.array([[0.0, 0, 0], [np.inf, 0, 0]])) is None
-    assert sharding.spatial_order(np.array([[0.0, 0, 0], [100.0, 0, 0]])) is None  # > 1024 cells along an axis
+    assert sharding.spatial_order(np.array([[0.0, 0, 0], [200.0, 0, 0]])) is None  # > 1024 cells along an axis
 
 
 def test_plugin_shards_gaussian_sources_cell_by_cell(monkeypatch):

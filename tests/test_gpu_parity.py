@@ -145,11 +145,12 @@ def test_cell_kernel_shapes_offsets_and_auto_policy():
     """cell_kernel beyond the golden set: clouds with thousands of points per cell (several tiles per
     cell, several cells per wave, ragged last tiles), distinct target and source clouds of different
     extent, a cloud far from the origin, D = 1 and 2, normalised rows and density; the auto policy
-    takes it when the clouds fill the cells (and not for a sparse cloud)."""
+    takes it when the clouds fill the cells (and not for a sparse cloud), with as many target tiles per
+    wave as the padding allows."""
     rs = np.random.RandomState(2024)
     for case_no, (D, n, m, side, offset) in enumerate([(3, 70000, 70000, 0.25, 0.0), (3, 40000, 90000, 0.3, 1.0e3),
                                                         (2, 50000, 33000, 1.0, -5.0), (1, 33000, 40000, 3.0, 0.0),
-                                                        (3, 100000, 100000, 1.0, 0.0)]):
+                                                        (3, 40000, 40000, 1.0, 0.0)]):
         same = case_no in (0, 4)
         y = (rs.rand(m, D) * side + offset).astype(np.float32)
         x = None if same else (rs.rand(n, D) * side * 0.8 + offset).astype(np.float32)
@@ -166,8 +167,8 @@ def test_cell_kernel_shapes_offsets_and_auto_policy():
         assert extra["device_kernel"] == "cell_kernel", extra
         assert rel_err(got[rows], want) <= TOL32, (case_no, rel_err(got[rows], want))
         auto, extra = run_plugin(case, y, x, None if dens else b, "float32")
-        # dense clouds (>= ~1000 points per cell) go to the cell kernel by themselves; 1e5 points in the
-        # unit cube (24 per cell: every other slot would be padding) stay with fast_kernel
+        # clouds that fill the cells go to the cell kernel by themselves; 4e4 points in the unit cube
+        # (40 per cell of side 0.103: more than 30 % of the tile slots would be padding) stay with fast_kernel
         assert extra["device_kernel"] == ("fast_kernel" if case_no == 4 else "cell_kernel"), (case_no, extra)
         assert rel_err(auto[rows], want) <= TOL32, (case_no, rel_err(auto[rows], want))
 
