@@ -10,14 +10,16 @@
 //     exp(-|x_i - y_j|^2) = U_i(S) * W_j(T) * exp(t_ij) ,   t_ij = 2 d_i.e_j ,  |t| <= dim h^2 / 2
 //         U_i(S) = exp(-|x_i - c_S|^2)          one exp per (target, source CELL)
 //         W_j(T) = exp(e_j.(2 D - e_j))          one exp per (source, target CELL)
-//         exp(t) = 1 + t + t^2/2 + O(t^3/6)      |t| <= 0.006  ->  truncation <= 3.6e-8
+//         exp(t) = 1 + t + t^2/2 + O(t^3/6)      |t| <= 0.016  ->  truncation <= 6.8e-7 (corner-to-corner
+//                                                pair of cells; ~1e-8 for a typical pair)
 // and 1 + t + t^2/2 is BILINEAR in monomials of d_i and of e_j -- sixteen of them for dim = 3:
 //     k = 0          1                         x  1
 //     k = 1 + 3a..   d_h, d_h, d_m  (coord a)  x  (2e)_h, (2e)_m, (2e)_h     two-way bf16 split: 16 bits,
-//                                                                          dropped terms <= 2^-17 |t| ~ 5e-8
-//     k = 10..15     d_a d_b                   x  2 e_a^2 | 4 e_a e_b       (<= 1.8e-5: one bf16 term)
+//                                                                          dropped terms <= 2^-17 |t| ~ 1.2e-7
+//     k = 10..15     d_a d_b                   x  2 e_a^2 | 4 e_a e_b       (<= 1.3e-4: one bf16 term)
 // i.e. ONE v_mfma_f32_32x32x16_bf16 per 32 sources x 32 targets hands the VALU the polynomial,
-// exact to ~1e-7 relative (the level of v_exp_f32 itself, random in sign).  What is left per pair is
+// to ~1e-7 relative for a typical pair and <= 1.3e-6 for the worst placed one (the class of the
+// difference form, whose squared distance carries eps32 * s), random in sign.  What is left per pair is
 // one FMA (p * W_j b_j into the tile sum); U multiplies the tile sum once.  Every pair is still
 // evaluated; nothing is truncated in space.  Accuracy against the fp64 oracle on the headline cloud:
 // see tests/test_gpu_parity.py::test_cell_kernel_*.
