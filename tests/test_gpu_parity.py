@@ -173,6 +173,34 @@ def test_cell_kernel_shapes_offsets_and_auto_policy():
         assert rel_err(auto[rows], want) <= TOL32, (case_no, rel_err(auto[rows], want))
 
 
+def test_cell_kernel_on_clustered_clouds():
+    """Cell occupancies from one point to tens of thousands (tight clusters on a thin uniform
+    background, duplicated points, a cluster exactly on a cell boundary): the tile lists, the padding to
+    TT tiles and the skipping of empty tiles must not depend on how full a cell is."""
+    rs = np.random.RandomState(77)
+    h = np.sqrt(2 * 0.016 / 3)
+    blobs = [rs.randn(30000, 3) * 0.004 + 0.31, rs.randn(5000, 3) * 0.02 + np.array([0.7, 0.2, 0.55]),
+             np.tile(rs.rand(1, 3), (700, 1)),                       # 700 copies of one point
+             np.floor(rs.rand(1, 3) * 5) * h + rs.randn(3000, 3) * 1e-4,   # straddles cell faces of the grid
+             rs.rand(1500, 3)]
+    y = np.concatenate(blobs).astype(np.float32)
+    rs.shuffle(y)
+    b = rs.randn(len(y), 1).astype(np.float32)
+    x = np.concatenate([y[:20000] + np.float32(1e-3), rs.rand(777, 3).astype(np.float32)])
+    rows = rs.choice(len(x), size=400, replace=False)
+    want = kmvp_oracle.product(kernel="gaussian", source_points=y.astype(np.float64), target_points=x[rows].astype(np.float64),
+                               source_signal=b.astype(np.float64))
+    for tiles in (1, 4, 8):
+        got, extra = run_plugin(dict(kernel="gaussian", D=3), y, x, b, "float32", fast_sqdists="cells", fast_tiles=tiles)
+        assert extra["device_kernel"] == "cell_kernel"
+        assert rel_err(got[rows], want) <= TOL32, (tiles, rel_err(got[rows], want))
+    same, extra = run_plugin(dict(kernel="gaussian", D=3, normalize_rows=True), y, None, b, "float32", fast_sqdists="cells")
+    rows = rs.choice(len(y), size=400, replace=False)
+    want = kmvp_oracle.product(kernel="gaussian", source_points=y.astype(np.float64), target_points=y[rows].astype(np.float64),
+                               source_signal=b.astype(np.float64), normalize_rows=True)
+    assert extra["device_kernel"] == "cell_kernel" and rel_err(same[rows], want) <= TOL32, rel_err(same[rows], want)
+
+
 def test_fast_sqdists_auto_policy():
     """auto: unit-cube gaussian -> matrix cores; same cloud blown up 100x, or 1/r -> difference form."""
     y, b = kmvp_oracle.uniform_cube(2000, 3)
