@@ -90,7 +90,7 @@ void kmvp_destroy(kmvp_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled, &c->y_scaled,
                     &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg,
-                    &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums})
+                    &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre})
     release(*b);
   for (int i = 0; i < 3; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -255,7 +255,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
   size_t t = 0;
   for (const DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled,
                           &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg,
-                          &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums})
+                          &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre})
     t += b->cap;
   return (int64_t)t;
 }

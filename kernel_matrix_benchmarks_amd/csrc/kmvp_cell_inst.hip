@@ -1,6 +1,7 @@
 // Instantiations of the cell-reduced Gaussian kernel (kmvp_cell.hpp): TT = target tiles of 32 per wave.
 #include "kmvp_internal.hpp"
 #include "kmvp_cell.hpp"
+#include "kmvp_cell64.hpp"
 
 namespace kmvp {
 
@@ -25,6 +26,12 @@ hipError_t launch_cell_gaussian(int sig, int TT, const CellArgs& args, dim3 grid
     case SIG_NORM: return launch_tt<SIG_NORM>(TT, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_cell64_gaussian(const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name) {
+  if (kernel_name) *kernel_name = "cell64_kernel";
+  hipLaunchKernelGGL((cell64_kernel<SIG_PRODUCT>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+  return hipGetLastError();
 }
 
 }  // namespace kmvp

@@ -17,8 +17,9 @@ constexpr int FAST_AUX_HALF = 65;
 constexpr int FAST_AUX_FLOATS = 160;
 constexpr int FAST_BBOX_BLOCKS = 256;
 
-__global__ void __launch_bounds__(256) fast_bbox_partial_kernel(const float* __restrict__ y, int64_t m,
-                                                               const float* __restrict__ x, int64_t n, int D,
+template <typename real>
+__global__ void __launch_bounds__(256) fast_bbox_partial_kernel(const real* __restrict__ y, int64_t m,
+                                                               const real* __restrict__ x, int64_t n, int D,
                                                                float* __restrict__ part /* [blocks][D][2] */) {
   __shared__ float lo[256], hi[256];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -26,13 +27,13 @@ __global__ void __launch_bounds__(256) fast_bbox_partial_kernel(const float* __r
   for (int d = 0; d < D; ++d) {
     float vmin = INFINITY, vmax = -INFINITY;
     for (int64_t i = first; i < m; i += stride) {
-      const float v = y[i * D + d];
+      const float v = (float)y[i * D + d];
       vmin = fminf(vmin, v);
       vmax = fmaxf(vmax, v);
     }
     if (x != nullptr)
       for (int64_t i = first; i < n; i += stride) {
-        const float v = x[i * D + d];
+        const float v = (float)x[i * D + d];
         vmin = fminf(vmin, v);
         vmax = fmaxf(vmax, v);
       }

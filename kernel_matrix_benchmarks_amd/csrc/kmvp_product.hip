@@ -5,6 +5,7 @@
 #include "kmvp_ctx.hpp"
 #include <vector>
 #include "kmvp_cell_pack.hpp"
+#include "kmvp_cell64_pack.hpp"
 #include "kmvp_cfast_pack.hpp"
 #include "kmvp_fast_pack.hpp"
 #include "kmvp_mfma_pack.hpp"
@@ -648,8 +649,8 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
 
 // Cell order of one cloud: keys -> radix sort; the sorted keys come back to the host, where the
 // tile lists are built (one pass over n keys, once per kmvp_set_points).
-int cell_sort(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, kmvp_ctx::DevBuf& perm,
-              std::vector<unsigned>& keys) {
+int cell_sort(kmvp_ctx* c, const void* pts, int64_t n, const CellGrid& grid, kmvp_ctx::DevBuf& perm,
+              std::vector<unsigned>& keys, kmvp_ctx::DevBuf* keys_dev = nullptr) {
   int rc;
   const int D = c->D;
   size_t tmp_bytes = 0;
@@ -661,11 +662,20 @@ int cell_sort(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, km
   unsigned* keys_out = keys_in + n;
   int* vals_in = (int*)(keys_out + n);
   void* tmp = (void*)((((uintptr_t)(vals_in + n)) + 255) & ~(uintptr_t)255);
-  hipLaunchKernelGGL(cell_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, pts, n, D, grid, keys_in, vals_in);
+  if (c->dtype == KMVP_F64)
+    hipLaunchKernelGGL(cell64_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, (const double*)pts, n, D, grid,
+                       keys_in, vals_in);
+  else
+    hipLaunchKernelGGL(cell_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, c->stream, (const float*)pts, n, D, grid,
+                       keys_in, vals_in);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, sort_pairs_u32(tmp, &tmp_bytes, keys_in, keys_out, vals_in, (int*)perm.p, n, c->stream));
   keys.resize((size_t)n);
   HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_out, keys_bytes, hipMemcpyDeviceToHost, c->stream));
+  if (keys_dev) {  // the float64 path keeps the sorted keys on the device too (source records are packed from them)
+    if ((rc = ensure(c, *keys_dev, keys_bytes))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(keys_dev->p, keys_out, keys_bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return KMVP_OK;
 }
@@ -673,7 +683,8 @@ int cell_sort(kmvp_ctx* c, const float* pts, int64_t n, const CellGrid& grid, km
 // Tiles of <= 32 points that never straddle a cell; every cell gets a multiple of `mult` tiles (the
 // extra ones are empty), so that the `mult` target tiles of a wavefront always share their cell.
 // Device layout of the list: [start][count][key], n_tiles entries each.
-int cell_tiles(kmvp_ctx* c, const std::vector<unsigned>& keys, int mult, kmvp_ctx::DevBuf& grp, int64_t* n_tiles) {
+int cell_tiles(kmvp_ctx* c, const std::vector<unsigned>& keys, int mult, kmvp_ctx::DevBuf& grp, int64_t* n_tiles,
+               int tile = CELL_TILE) {
   const int64_t n = (int64_t)keys.size();
   std::vector<int> start, count;
   std::vector<unsigned> gkey;
@@ -684,9 +695,9 @@ int cell_tiles(kmvp_ctx* c, const std::vector<unsigned>& keys, int mult, kmvp_ct
     int64_t e = p + 1;
     while (e < n && keys[(size_t)e] == keys[(size_t)p]) ++e;
     int tiles = 0;
-    for (int64_t t = p; t < e; t += CELL_TILE, ++tiles) {
+    for (int64_t t = p; t < e; t += tile, ++tiles) {
       start.push_back((int)t);
-      count.push_back((int)std::min<int64_t>(CELL_TILE, e - t));
+      count.push_back((int)std::min<int64_t>(tile, e - t));
       gkey.push_back(keys[(size_t)p]);
     }
     for (; tiles % mult; ++tiles) {
@@ -751,9 +762,9 @@ int cell_prepare(kmvp_ctx* c, int TT) {
   }
   int rc;
   std::vector<unsigned> keys;
-  if ((rc = cell_sort(c, (const float*)c->y_raw.p, c->M, grid, c->cell_sperm, keys))) return rc;
+  if ((rc = cell_sort(c, c->y_raw.p, c->M, grid, c->cell_sperm, keys))) return rc;
   if ((rc = cell_tiles(c, keys, 1, c->cell_sgrp, &c->cell_m_tiles))) return rc;
-  if (!c->same_points && (rc = cell_sort(c, (const float*)c->x_raw.p, c->N, grid, c->cell_tperm, keys))) return rc;
+  if (!c->same_points && (rc = cell_sort(c, c->x_raw.p, c->N, grid, c->cell_tperm, keys))) return rc;
   if (TT == 0) {
     TT = 2;
     for (int t : {8, 4}) {
@@ -868,6 +879,144 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   return finish_product(c, (int64_t)NE * N, N, N, E, sig);
 }
 
+// ---- float64 cell path (kmvp_cell64.hpp): Gaussian, D <= 3, E == 1, plain product ----------------------
+
+// Grid, cell order, target tiles of 64 and the list of source cells for the current points.
+int cell64_prepare(kmvp_ctx* c) {
+  if (c->cell_ver == c->points_ver && c->cell_state != 0) return KMVP_OK;
+  c->cell_ver = c->points_ver;
+  c->cell_state = -1;
+  const int D = c->D;
+  if (D > CELL_MAX_D || !(c->cloud_radius2 < INFINITY) || c->N > 0x3fffffff || c->M > 0x3fffffff) return KMVP_OK;
+  float aux[FAST_AUX_FLOATS];
+  HIP_TRY(c, hipMemcpyAsync(aux, c->aux.p, sizeof(aux), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  CellGrid grid;
+  grid.h = (float)std::sqrt(2.0 * CELL64_T_MAX / (double)D);
+  grid.inv_h = 1.f / grid.h;
+  for (int a = 0; a < 3; ++a) {
+    grid.lo[a] = 0.f;
+    grid.g[a] = 1;
+  }
+  for (int a = 0; a < D; ++a) {
+    const float half = aux[FAST_AUX_HALF + a];
+    grid.lo[a] = aux[a] - half;
+    const double cells = std::floor(2.0 * half / grid.h) + 1.0;
+    if (!(cells <= CELL_MAX_GRID)) return KMVP_OK;
+    grid.g[a] = (int)cells;
+  }
+  int rc;
+  std::vector<unsigned> keys;
+  if ((rc = cell_sort(c, c->y_raw.p, c->M, grid, c->cell_sperm, keys, &c->cell_skey))) return rc;
+  // source cells: [first record, count] and centres
+  std::vector<int> runs;
+  std::vector<double> centres;
+  for (int64_t p = 0; p < c->M;) {
+    int64_t e = p + 1;
+    while (e < c->M && keys[(size_t)e] == keys[(size_t)p]) ++e;
+    runs.push_back((int)p);
+    runs.push_back((int)(e - p));
+    for (int a = 0; a < 3; ++a) centres.push_back(a < D ? cell64_centre(keys[(size_t)p], a, grid) : 0.0);
+    centres.push_back(0.0);
+    p = e;
+  }
+  c->cell_m_tiles = (int64_t)runs.size() / 2;  // number of source cells
+  if ((rc = ensure(c, c->cell_sgrp, runs.size() * sizeof(int)))) return rc;
+  if ((rc = ensure(c, c->cell_scentre, centres.size() * sizeof(double)))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->cell_sgrp.p, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->cell_scentre.p, centres.data(), centres.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->same_points && (rc = cell_sort(c, c->x_raw.p, c->N, grid, c->cell_tperm, keys))) return rc;
+  if ((rc = cell_tiles(c, keys, 1, c->cell_tgrp, &c->cell_n_tiles, CELL64_TILE))) return rc;
+  c->cell_tt = 1;
+  for (int a = 0; a < 3; ++a) {
+    c->cell_lo[a] = grid.lo[a];
+    c->cell_g[a] = grid.g[a];
+  }
+  c->cell_h = grid.h;
+  c->cell_state = 1;
+  c->packed_layout = -1;
+  return KMVP_OK;
+}
+
+int run_product_cell64(kmvp_ctx* c, int sig) {
+  const int D = c->D;
+  const int64_t N = c->N, M = c->M;
+  const int64_t n_tiles = round_up(c->cell_n_tiles, WAVES_PER_BLOCK);
+  const int64_t n_slots = n_tiles * CELL64_TILE;
+  const int64_t tile_blocks = n_tiles / WAVES_PER_BLOCK;
+  const int n_scells = (int)c->cell_m_tiles;
+  int rc;
+  CellGrid grid;
+  for (int a = 0; a < 3; ++a) {
+    grid.lo[a] = c->cell_lo[a];
+    grid.g[a] = c->cell_g[a];
+  }
+  grid.h = c->cell_h;
+  grid.inv_h = 1.f / c->cell_h;
+  // segments of whole source cells: enough workgroups for a few rounds of the chip
+  int64_t seg = c->opt_segments > 0 ? c->opt_segments : (8192 + tile_blocks - 1) / tile_blocks;
+  seg = std::max<int64_t>(1, std::min<int64_t>(seg, n_scells));
+  const int seg_cells = (int)((n_scells + seg - 1) / seg);
+  const int segments = (n_scells + seg_cells - 1) / seg_cells;
+
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
+                         c->packed_layout != LAYOUT_CELL64;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  const double* x_raw = (const double*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int* tperm = (const int*)(c->same_points ? c->cell_sperm.p : c->cell_tperm.p);
+  const int* tgrp = (const int*)c->cell_tgrp.p;
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_slots * 4 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->cell_tmeta, (size_t)n_tiles * 4 * sizeof(double)))) return rc;
+    if ((rc = ensure(c, c->cell_slot, (size_t)N * sizeof(int)))) return rc;
+    hipLaunchKernelGGL(pack_cell64_targets_kernel, dim3((unsigned)n_tiles), dim3(CELL64_TILE), 0, c->stream, x_raw, tperm,
+                       tgrp, tgrp + c->cell_n_tiles, (const unsigned*)(tgrp + 2 * c->cell_n_tiles), c->cell_n_tiles, D,
+                       grid, (double*)c->xs.p, (double*)c->cell_tmeta.p, (int*)c->cell_slot.p);
+  }
+  if (sig_stale) {
+    const int64_t m_alloc = M + 64;  // zero records behind the last cell: the W pass reads whole groups of 64
+    if ((rc = ensure(c, c->rec, (size_t)m_alloc * 4 * sizeof(double)))) return rc;
+    hipLaunchKernelGGL(pack_cell64_sources_kernel, dim3(blocks_for(m_alloc)), dim3(256), 0, c->stream,
+                       (const double*)c->y_raw.p, sig == SIG_DENSITY ? (const double*)nullptr : (const double*)c->b_raw.p,
+                       (const int*)c->cell_sperm.p, (const unsigned*)c->cell_skey.p, M, m_alloc, D, grid, (double*)c->rec.p);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = K_GAUSSIAN;
+  c->packed_sig = sig;
+  c->packed_layout = LAYOUT_CELL64;
+  c->packed_T = 1;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * n_slots * sizeof(double)))) return rc;
+  Cell64Args a;
+  a.xd = (const double*)c->xs.p;
+  a.tmeta = (const double*)c->cell_tmeta.p;
+  a.srec = (const double*)c->rec.p;
+  a.scell = (const int*)c->cell_sgrp.p;
+  a.scentre = (const double*)c->cell_scentre.p;
+  a.part = (double*)c->part.p;
+  a.n_slots = n_slots;
+  a.n_scells = n_scells;
+  a.seg_cells = seg_cells;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  const dim3 grid_dim((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, mark(c, 0));
+  HIP_TRY(c, launch_cell64_gaussian(a, grid_dim, c->stream, &c->last_kernel_name));
+  HIP_TRY(c, mark(c, 1));
+
+  if ((rc = ensure(c, c->sums, (size_t)N * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->cell_sums, (size_t)n_slots * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(n_slots)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->cell_sums.p, n_slots, segments);
+  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for(N)), dim3(256), 0, c->stream,
+                     (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, 1);
+  HIP_TRY(c, hipGetLastError());
+  return finish_product(c, N, N, N, 1, sig);
+}
+
 // bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
 // to augmented bf16 rows / LDS tile images, sums come back as fp32 partials.
 int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
@@ -967,13 +1116,20 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
 // synchronises.
 int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D) {
   c->cloud_radius2 = INFINITY;
-  if (dtype != KMVP_F32 || D > FAST_MAX_D || M <= 0 || N <= 0) return KMVP_OK;
+  // float32: inputs of the split-bf16 paths and of their "auto" rule; float64: the grid of the cell path (D <= 3)
+  const bool f64_cells = dtype == KMVP_F64 && D <= CELL_MAX_D;
+  if ((dtype != KMVP_F32 && !f64_cells) || D > FAST_MAX_D || M <= 0 || N <= 0) return KMVP_OK;
   int rc;
   if ((rc = ensure(c, c->aux, (FAST_AUX_FLOATS + 2 * (size_t)FAST_BBOX_BLOCKS * D) * sizeof(float)))) return rc;
   float* part = (float*)c->aux.p + FAST_AUX_FLOATS;
-  hipLaunchKernelGGL(fast_bbox_partial_kernel, dim3(FAST_BBOX_BLOCKS), dim3(256), 0, c->stream,
-                     (const float*)c->y_raw.p, M, c->same_points ? (const float*)nullptr : (const float*)c->x_raw.p, N,
-                     D, part);
+  if (f64_cells)  // box in float32 (the cells only need it to a grid spacing), outward rounding is not needed: keys are clamped
+    hipLaunchKernelGGL((fast_bbox_partial_kernel<double>), dim3(FAST_BBOX_BLOCKS), dim3(256), 0, c->stream,
+                       (const double*)c->y_raw.p, M, c->same_points ? (const double*)nullptr : (const double*)c->x_raw.p, N,
+                       D, part);
+  else
+    hipLaunchKernelGGL((fast_bbox_partial_kernel<float>), dim3(FAST_BBOX_BLOCKS), dim3(256), 0, c->stream,
+                       (const float*)c->y_raw.p, M, c->same_points ? (const float*)nullptr : (const float*)c->x_raw.p, N,
+                       D, part);
   hipLaunchKernelGGL(fast_center_kernel, dim3(1), dim3(FAST_BBOX_BLOCKS), 0, c->stream, (const float*)part, D,
                      (float*)c->aux.p);
   HIP_TRY(c, hipGetLastError());
@@ -1060,6 +1216,16 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     }
     if (c->opt_fast == 1 || (c->opt_fast < 0 && global_ok)) return run_product_fast(c, kernel, sig);
     if (centred_ok && (c->opt_fast == 2 || c->opt_fast < 0)) return run_product_cfast(c, kernel, sig);
+  }
+  if (c->dtype == KMVP_F64 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && (c->density || c->E == 1) && sig != SIG_NORM &&
+      c->centre_ver == c->points_ver &&
+      (c->opt_fast == 3 || (c->opt_fast < 0 && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
+    // float64 cell form (kmvp_cell64.hpp): 12 fp64 instructions per pair instead of ~23
+    int rc = cell64_prepare(c);
+    if (rc) return rc;
+    if (c->cell_state == 1 &&
+        (c->opt_fast == 3 || (double)c->cell_n_tiles * CELL64_TILE <= CELL_AUTO_MAX_PAD * (double)c->N))
+      return run_product_cell64(c, sig);
   }
   if (c->D <= LOWD_MAX_D && !c->density && c->E > LOWD_MAX_E)  // low D, many signal columns
     return c->dtype == KMVP_F64 ? run_product_blocked<double>(c, kernel, sig) : run_product_blocked<float>(c, kernel, sig);

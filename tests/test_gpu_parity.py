@@ -173,6 +173,70 @@ def test_cell_kernel_shapes_offsets_and_auto_policy():
         assert rel_err(auto[rows], want) <= TOL32, (case_no, rel_err(auto[rows], want))
 
 
+CELLS64 = [c for c in CELLS if not c["normalize_rows"]]
+
+
+@pytest.mark.parametrize("case", CELLS64, ids=[c["name"] for c in CELLS64])
+def test_cell64_kernel_matches_reference(case, expected):
+    """float64 cell form (kmvp_cell64.hpp: exp() range-reduced by grid cells, degree-8 remainder): held to the
+    float64 tolerance on the golden Gaussian cases."""
+    y, x, b = golden_cases.make_inputs(case)
+    want = expected[f"{case['name']}/f64"]
+    got, extra = run_plugin(case, y, x, b, np.float64, fast_sqdists="cells")
+    assert extra["device_kernel"] == "cell64_kernel"
+    assert rel_err(got, want) <= TOL64, rel_err(got, want)
+
+
+def test_cell64_kernel_at_scale_and_in_the_solver():
+    """1e5 points (BASELINE config 5's shape): the auto rule takes the float64 cell form, the product matches
+    the oracle on a row subset for x == y and x != y, clustered clouds included, and conjugate gradients on
+    that operator reach the residual."""
+    rs = np.random.RandomState(64)
+    n = 100_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    rows = rs.choice(n, size=200, replace=False)
+    want = kmvp_oracle.product(kernel="gaussian", source_points=y, target_points=y[rows], source_signal=b)
+    got, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, np.float64)
+    assert extra["device_kernel"] == "cell64_kernel"
+    assert rel_err(got[rows], want) <= TOL64, rel_err(got[rows], want)
+    # distinct clouds, clusters and duplicates, D = 2
+    y2 = np.concatenate([rs.randn(30000, 2) * 0.01 + 0.3, rs.rand(20000, 2), np.tile(rs.rand(1, 2), (500, 1))])
+    x2 = np.concatenate([rs.rand(33000, 2) * 1.3 - 0.1, y2[:777]])
+    b2 = rs.randn(len(y2), 1)
+    rows = rs.choice(len(x2), size=200, replace=False)
+    want = kmvp_oracle.product(kernel="gaussian", source_points=y2, target_points=x2[rows], source_signal=b2)
+    got, extra = run_plugin(dict(kernel="gaussian", D=2), y2, x2, b2, np.float64, fast_sqdists="cells")
+    assert extra["device_kernel"] == "cell64_kernel"
+    assert rel_err(got[rows], want) <= TOL64, rel_err(got[rows], want)
+    # the solver on that operator (x := K b0, then solve K b = x)
+    m = 40000
+    ys = rs.rand(m, 3)
+    b0 = rs.randn(m, 1)
+    algo = MI355XProduct(kernel="gaussian", dimension=3, precision=np.float64)
+    try:
+        algo.prepare_data(source_points=ys, target_points=ys, same_points=True)
+        algo.prepare_query(source_signal=b0)
+        algo.query()
+        a = algo.get_result()
+        assert algo.get_additional()["device_kernel"] == "cell64_kernel"
+    finally:
+        algo.done()
+    solver = MI355XSolver(kernel="gaussian", dimension=3, precision=np.float64, rtol=1e-6, maxit=3000)
+    try:
+        solver.prepare_data(source_points=ys)
+        solver.fit()
+        solver.prepare_query(target_signal=a)
+        solver.query()
+        extra = solver.get_additional()
+        assert extra["cg_converged"] and extra["cg_relative_residual"] <= 1e-6, extra
+        assert solver._ctx.last_kernel_name == "cell64_kernel"
+        true = np.linalg.norm(c_oracle.product(kernel="gaussian", source_points=ys, source_signal=solver.get_result(),
+                                               rows=np.arange(256)) - a[:256]) / np.linalg.norm(a[:256])
+        assert true <= 1e-5, true  # the residual holds against the oracle's operator too (256 rows)
+    finally:
+        solver.done()
+
+
 def test_cell_kernel_on_clustered_clouds():
     """Cell occupancies from one point to tens of thousands (tight clusters on a thin uniform
     background, duplicated points, a cluster exactly on a cell boundary): the tile lists, the padding to
