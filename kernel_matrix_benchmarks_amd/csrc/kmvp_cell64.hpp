@@ -8,12 +8,13 @@
 //
 // The difference-form kernel spends ~23 fp64 instructions per pair (6 for the squared distance, ~16 for
 // the table-and-polynomial exp of kexp_neg_f64, 1 FMA); here a pair costs 3 (t) + 8 (Horner) + 1 (FMA)
-// plus two v_readlane.  Cells of side sqrt(2 * 0.05 / D) (0.18 for D = 3).
+// (kmvp_lowd.hpp's count per pair: SQ_INSTS_VALU 23.4 against 13.7 here, padding and per-cell work included).
+// Cells of side sqrt(2 * 0.05 / D) (0.18 for D = 3).
 //
 // Mapping (as lowd_kernel): two targets per lane, a wavefront = one tile of 128 targets of ONE cell (cells
 // are padded to whole tiles), sources wave-uniform.  Per source cell the wave computes U, then walks
 // the cell's sources 64 at a time: W_j b_j with the source on the lane, then for each source the record
-// (2e, b) arrives through wave-uniform loads (scalar cache) and W_j b_j through v_readlane.
+// (2e, b) arrives through wave-uniform loads (scalar cache) and W_j b_j through a broadcast LDS read.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,7 +24,7 @@
 
 namespace kmvp {
 
-constexpr int CELL64_TPL = 2;                  // targets per lane: halves the scalar-cache and v_readlane traffic per pair
+constexpr int CELL64_TPL = 2;                  // targets per lane: halves the scalar-cache and LDS traffic per pair
 constexpr int CELL64_TILE = 64 * CELL64_TPL;  // targets per tile = one wavefront
 constexpr double CELL64_T_MAX = 0.05;  // bound on |2 d.e|
 
@@ -46,12 +47,6 @@ struct Cell64Args {
 };
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double cell64_readlane(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
 
 // exp(t) for |t| <= CELL64_T_MAX by Horner (degree 8)
 __device__ __forceinline__ double cell64_exp(double t) {
