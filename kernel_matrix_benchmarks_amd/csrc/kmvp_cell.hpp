@@ -96,9 +96,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
   const int h = lane >> 5;
   const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
 
-  // TT = 8 re-reads the targets' offsets when U is recomputed (every ~8 source tiles) instead of
-  // holding them: 24 registers decide between three and four waves per SIMD there
+  // TT = 8 keeps the targets' offsets in LDS and re-reads them when U is recomputed (once per source
+  // cell) instead of holding them: 24 registers decide between three and four waves per SIMD there
   constexpr bool HOLD_D = TT < 8;
+  __shared__ __attribute__((aligned(16))) float dsh[HOLD_D ? 1 : WAVES_PER_BLOCK][HOLD_D ? 1 : TT][CELL_TILE][4];
   float dl[HOLD_D ? TT : 1][3], cT[3], U[TT];
   bf16x8 xb[TT];
   bool live[TT];  // false: one of the empty tiles that pad a cell to a multiple of TT tiles (wave-uniform)
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       if constexpr (HOLD_D) dl[tt][c] = v[c];
+      else if (h == 0) dsh[wave][tt][r][c] = v[c];
       if (tt == 0) cT[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[c])));  // one cell per wave
       const float dh = (float)(__bf16)v[c];
       const float dm = (float)(__bf16)(v[c] - dh);
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
 #pragma unroll
           for (int tt = 0; tt < TT; ++tt) {
             f32x4 dv;
-            if constexpr (!HOLD_D) dv = *reinterpret_cast<const f32x4*>(a.xd + ((tile0 + tt) * CELL_TILE + r) * 4);
+            if constexpr (!HOLD_D) dv = *reinterpret_cast<const f32x4*>(&dsh[wave][tt][r][0]);
             float s2 = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
