@@ -600,6 +600,7 @@ def test_single_rank_rccl_communicator():
     cases = [("gaussian", True, _lib.KMVP_F32, 0, "lowd_kernel"), ("gaussian", True, _lib.KMVP_F32, 1, "fast_kernel"),
              ("inverse-distance", False, _lib.KMVP_F32, 2, "cfast_kernel"),
              ("gaussian", False, _lib.KMVP_F32, 3, "cell_kernel"), ("gaussian", True, _lib.KMVP_F32, 3, "cell_kernel"),
+             ("gaussian", False, _lib.KMVP_F64, 3, "cell64_kernel"),
              ("absolute-exponential", True, _lib.KMVP_F64, 0, "lowd_kernel")]
     for kernel, norm, dtype, fast, kname in cases:
         npdt = np.float64 if dtype == _lib.KMVP_F64 else np.float32
@@ -829,6 +830,35 @@ def test_long_cg_graph_replay_equals_plain_launches():
             ctx.close()
             os.environ.pop("KMVP_NO_GRAPH", None)
         assert iters == 1000
+        outs.append(sol)
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_long_cg_graph_replay_on_the_cell_operator():
+    """The same with the float64 cell operator (N >= 32768): its per-iteration launches (signal re-pack, pair
+    loop, segment sums, gather) are captured and replayed like any other product."""
+    import os
+
+    n = 33000
+    rs = np.random.RandomState(9)
+    y = rs.rand(n, 3)
+    a = rs.randn(n, 1)
+    outs = []
+    for no_graph in (False, True):
+        if no_graph:
+            os.environ["KMVP_NO_GRAPH"] = "1"
+        else:
+            os.environ.pop("KMVP_NO_GRAPH", None)
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_option("fast_sqdists", 3)  # 33000 points sit at the padding limit of the auto rule
+            ctx.set_points(y, None, _lib.KMVP_F64)
+            sol, iters, resid, ok = ctx.cg_solve("gaussian", a, 1e-15, 560)  # unreachable tolerance: runs to maxit
+            assert ctx.last_kernel_name == "cell64_kernel"
+        finally:
+            ctx.close()
+            os.environ.pop("KMVP_NO_GRAPH", None)
+        assert iters == 560
         outs.append(sol)
     assert np.array_equal(outs[0], outs[1])
 
