@@ -265,6 +265,31 @@ def test_cell_kernel_on_clustered_clouds():
     assert extra["device_kernel"] == "cell_kernel" and rel_err(same[rows], want) <= TOL32, rel_err(same[rows], want)
 
 
+def test_cell_paths_follow_new_points_and_signals_in_one_context():
+    """One context, points and signals replaced in turn (float32 and float64 cell paths): the cell order belongs
+    to a points version, the source image to a signal version -- neither may be reused across an upload."""
+    rs = np.random.RandomState(31)
+    for dtype, npdt, tol, kname in ((_lib.KMVP_F32, np.float32, TOL32, "cell_kernel"), (_lib.KMVP_F64, np.float64, TOL64, "cell64_kernel")):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_option("fast_sqdists", 3)
+            for n, side in ((40000, 0.4), (36000, 0.7), (40000, 0.4)):
+                y = (rs.rand(n, 3) * side).astype(npdt)
+                ctx.set_points(y, None, dtype)
+                rows = rs.choice(n, size=100, replace=False)
+                for _ in range(2):
+                    b = rs.randn(n, 1).astype(npdt)
+                    ctx.set_signal(b)
+                    ctx.run("gaussian", False)
+                    got = ctx.get_result(n, 1)
+                    assert ctx.last_kernel_name == kname
+                    want = kmvp_oracle.product(kernel="gaussian", source_points=y.astype(np.float64),
+                                               target_points=y[rows].astype(np.float64), source_signal=b.astype(np.float64))
+                    assert rel_err(got[rows], want) <= tol, (kname, n, rel_err(got[rows], want))
+        finally:
+            ctx.close()
+
+
 def test_fast_sqdists_auto_policy():
     """auto: unit-cube gaussian -> matrix cores; same cloud blown up 100x, or 1/r -> difference form."""
     y, b = kmvp_oracle.uniform_cube(2000, 3)
