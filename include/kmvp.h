@@ -81,6 +81,13 @@ const char* kmvp_last_error(const kmvp_ctx* ctx);
 int kmvp_set_points(kmvp_ctx* ctx, const void* y, int64_t M, const void* x_or_null, int64_t N,
                     int D, int dtype, int64_t j_offset, int64_t M_total);
 
+/* BaseAlgorithm.fit (base.py:84, bruteforce.py:113-120: the reference builds its kernel matrix
+ * there, timed as build_time).  Nothing of the matrix is ever built here; what CAN be built from the
+ * points alone is: for the Gaussian on clouds that qualify for the cell form (fast_sqdists 3 / auto),
+ * the grid, the cell order (radix sort) and the tile lists.  kernel: 0 gaussian, 1 absexp, 2 invdist.
+ * Optional: the first query does the same work when fit was not called. */
+int kmvp_fit(kmvp_ctx* ctx, int kernel);
+
 /* BaseProduct.prepare_query (base.py:86-98, bruteforce.py:122-128).
  *   b: (M,E) row-major signal of this shard in the dtype given to
  *   kmvp_set_points, or NULL for density estimation (b == 1, E must be 1). */

@@ -27,6 +27,7 @@ SYMBOLS = [
     ("kmvp_last_error", _c.c_char_p, [_c.c_void_p]),
     ("kmvp_set_points", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int64,
                                    _c.c_int, _c.c_int, _c.c_int64, _c.c_int64]),
+    ("kmvp_fit", _c.c_int, [_c.c_void_p, _c.c_int]),
     ("kmvp_set_signal", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
     ("kmvp_gaussian", _c.c_int, [_c.c_void_p]),
     ("kmvp_gaussian_norm", _c.c_int, [_c.c_void_p]),
@@ -123,6 +124,9 @@ class Context:
         self._check(self._lib.kmvp_set_points(
             self._ctx, y.ctypes.data, M, None if x is None else x.ctypes.data, N, D, dtype_code_,
             int(j_offset), int(M if M_total is None else M_total)))
+
+    def fit(self, kernel):
+        self._check(self._lib.kmvp_fit(self._ctx, {"gaussian": 0, "absolute-exponential": 1, "inverse-distance": 2}[kernel]))
 
     def set_signal(self, b):
         if b is None:

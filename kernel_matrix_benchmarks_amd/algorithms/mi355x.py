@@ -129,7 +129,9 @@ class MI355XProduct(BaseProduct):
 
     # -- timed ---------------------------------------------------------------------
     def fit(self):
-        """Nothing to pre-compute: the kernel matrix is never formed."""
+        """The kernel matrix is never formed; what the points alone determine (grid, cell order and tile
+        lists of the Gaussian cell kernels) is built here, as the reference builds its structure in fit()."""
+        self._ctx.fit(self.kernel)
 
     def query(self):
         # synchronous: the device (and the all-reduce) is done when this returns

@@ -134,6 +134,14 @@ int kmvp_set_points(kmvp_ctx* c, const void* y, int64_t M, const void* x_or_null
   return KMVP_OK;
 }
 
+int kmvp_fit(kmvp_ctx* c, int kernel) {
+  if (!c) return KMVP_E_INVALID;
+  if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
+  if (kernel < 0 || kernel > 2) return fail(c, KMVP_E_INVALID, "kernel must be 0, 1 or 2");
+  HIP_TRY(c, hipSetDevice(c->device));
+  return prepare_points(c, kernel);
+}
+
 int kmvp_set_signal(kmvp_ctx* c, const void* b_or_null, int E) {
   if (!c) return KMVP_E_INVALID;
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points must come first");

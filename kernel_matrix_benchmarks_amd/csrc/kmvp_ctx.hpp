@@ -170,6 +170,7 @@ void release(DevBuf& b);
 // bounding box of the freshly uploaded clouds (asynchronous on the context's stream)
 int run_product(kmvp_ctx* c, int kernel, bool normalise);
 int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D);
+int prepare_points(kmvp_ctx* c, int kernel);  // kmvp_fit: whatever can be built from the points alone
 
 // kmvp_solvers.hip
 int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, int maxit, double* out_b,

@@ -1139,6 +1139,24 @@ int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D) {
   return KMVP_OK;
 }
 
+// kmvp_fit: the cell structures of the Gaussian paths depend on the points only, so they can be built
+// before any signal exists (the conditions are those of run_product() with E = 1 assumed).
+int prepare_points(kmvp_ctx* c, int kernel) {
+  if (kernel != K_GAUSSIAN || c->D > CELL_MAX_D || c->N == 0 || c->M == 0 || c->centre_ver != c->points_ver ||
+      c->opt_fast == 0 || c->opt_fast == 1 || c->opt_fast == 2)
+    return KMVP_OK;
+  const bool big = c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS;
+  if (c->dtype == KMVP_F32) {
+    const float sc = scale_for<float>(kernel);
+    const bool global_ok = c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
+    if (c->opt_fast == 3 || (global_ok && big))
+      return cell_prepare(c, c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : 0));
+  } else if (c->dtype == KMVP_F64) {
+    if (c->opt_fast == 3 || big) return cell64_prepare(c);
+  }
+  return KMVP_OK;
+}
+
 int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   if (!c) return KMVP_E_INVALID;
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
