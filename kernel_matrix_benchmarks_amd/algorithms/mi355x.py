@@ -223,14 +223,7 @@ class MI355XSolver(BaseSolver):
             # is sharded over the sources and summed by the product's own all-reduce
             self._shard = sharding.shard_range(self.M, self.comm.rank, world)
             lo, hi = self._shard
-            # Gaussian (no index-based rule): shard the sources cell by cell instead of in the caller's
-            # order -- every rank derives the same permutation from the full cloud it was handed
-            self._order = (sharding.spatial_order(y) if self.kernel == "gaussian" and self._host_dtype == np.float32
-                           else None)
-            if self._order is not None:
-                targets = y if x is None else x
-                y = y[self._order]
-                x = targets
+            # (the sources keep the caller's order here: a rank's signal is a slice of the replicated Krylov vector)
             self.comm.attach(self._ctx)
             self._ctx.set_option("same_points_global", 1)
             self._ctx.set_points(np.ascontiguousarray(y[lo:hi]), y, self._dtype_code, j_offset=lo, M_total=self.M)
@@ -239,7 +232,8 @@ class MI355XSolver(BaseSolver):
             self._ctx.set_points(y, None, self._dtype_code)
 
     def fit(self):
-        """Nothing to factorise."""
+        """Nothing to factorise; the cell order of the float64 Gaussian operator is built here (kmvp_fit)."""
+        self._ctx.fit(self.kernel)
 
     def prepare_query(self, *, target_signal):
         a = np.ascontiguousarray(target_signal, dtype=self._host_dtype)

@@ -199,6 +199,14 @@ def test_plugin_shards_gaussian_sources_cell_by_cell(monkeypatch):
         assert np.array_equal(ys, y.astype(np.float32)[order][lo:hi])
         assert np.array_equal(xs, y.astype(np.float32))  # all targets, caller's order
         assert np.array_equal(calls["signal"], b.astype(np.float32)[order][lo:hi])
+    # the solver never reorders: a rank's signal is the slice [lo, hi) of the replicated Krylov vector
+    for precision in ("float32", np.float64):
+        solver = mi355x.MI355XSolver(kernel="gaussian", dimension=3, normalize_rows=False, precision=precision, comm=FakeComm())
+        solver.prepare_data(source_points=y)
+        ys, xs, j_offset, m_total = calls["points"]
+        dt = np.float32 if precision == "float32" else np.float64
+        assert (j_offset, m_total) == (lo, 999)
+        assert np.array_equal(ys, y.astype(dt)[lo:hi]) and np.array_equal(xs, y.astype(dt))
 
 
 def test_container_roundtrip(tmp_path):
