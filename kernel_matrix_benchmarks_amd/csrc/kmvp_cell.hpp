@@ -4,7 +4,7 @@
 // v_exp_f32 per pair -- 70 % of its issue cycles, and the cap of every exp-per-pair kernel on this
 // chip (~1.9e13 pairs/s).  Here the exponential itself is range-reduced the way a math library does
 // it, with the cells of a regular grid as the reduction table.  Both clouds are binned into cells of
-// side h; a target i in a cell with centre c_T and a source j in a cell with centre c_S are
+// side h (per axis: the bounding box divided into equal cells within the accuracy bound); a target i in a cell with centre c_T and a source j in a cell with centre c_S are
 //     x_i = c_T + d_i ,   y_j = c_S + e_j ,   D = c_T - c_S ,   |d|, |e| <= h sqrt(dim) / 2
 //     |x_i - y_j|^2 = |D + d_i|^2  +  (|e_j|^2 - 2 D.e_j)  -  2 d_i.e_j
 //     exp(-|x_i - y_j|^2) = U_i(S) * W_j(T) * exp(t_ij) ,   t_ij = 2 d_i.e_j ,  |t| <= dim h^2 / 2
@@ -57,12 +57,12 @@ constexpr int CELL_MAX_GRID = 1024;   // cells per axis (10 bits of the key each
 
 struct CellGrid {
   float lo[3];
-  float h, inv_h;
+  float h[3], inv_h[3];  // per axis: the box extent divided into equal cells of side <= the accuracy bound
   int g[3];
 };
 
 __host__ __device__ inline float cell_centre(unsigned key, int a, const CellGrid& grid) {
-  return grid.lo[a] + ((float)((key >> (10 * a)) & 1023u) + 0.5f) * grid.h;
+  return grid.lo[a] + ((float)((key >> (10 * a)) & 1023u) + 0.5f) * grid.h[a];
 }
 
 struct CellArgs {

@@ -29,7 +29,7 @@ constexpr int CELL64_TILE = 64 * CELL64_TPL;  // targets per tile = one wavefron
 constexpr double CELL64_T_MAX = 0.05;  // bound on |2 d.e|
 
 __host__ __device__ inline double cell64_centre(unsigned key, int a, const CellGrid& grid) {
-  return (double)grid.lo[a] + ((double)((key >> (10 * a)) & 1023u) + 0.5) * (double)grid.h;
+  return (double)grid.lo[a] + ((double)((key >> (10 * a)) & 1023u) + 0.5) * (double)grid.h[a];
 }
 
 struct Cell64Args {

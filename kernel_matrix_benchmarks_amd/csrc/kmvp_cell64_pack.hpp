@@ -13,7 +13,7 @@ __global__ void cell64_keys_kernel(const double* __restrict__ p, int64_t n, int 
   if (i >= n) return;
   unsigned key = 0;
   for (int a = 0; a < D; ++a) {
-    int c = (int)floor((p[i * D + a] - (double)grid.lo[a]) * (double)grid.inv_h);
+    int c = (int)floor((p[i * D + a] - (double)grid.lo[a]) * (double)grid.inv_h[a]);
     c = c < 0 ? 0 : (c >= grid.g[a] ? grid.g[a] - 1 : c);
     key |= (unsigned)c << (10 * a);
   }

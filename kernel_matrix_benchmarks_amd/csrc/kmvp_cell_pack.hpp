@@ -12,7 +12,7 @@ __global__ void cell_keys_kernel(const float* __restrict__ p, int64_t n, int D, 
   if (i >= n) return;
   unsigned key = 0;
   for (int a = 0; a < D; ++a) {
-    int c = (int)floorf((p[i * D + a] - grid.lo[a]) * grid.inv_h);
+    int c = (int)floorf((p[i * D + a] - grid.lo[a]) * grid.inv_h[a]);
     c = c < 0 ? 0 : (c >= grid.g[a] ? grid.g[a] - 1 : c);
     key |= (unsigned)c << (10 * a);
   }

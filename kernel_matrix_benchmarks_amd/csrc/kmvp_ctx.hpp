@@ -132,7 +132,7 @@ struct kmvp_ctx {
   uint64_t cell_ver = 0;                  // points version the cell structures belong to
   int cell_state = 0;                     // for cell_ver: 0 not examined, 1 built, -1 the path does not apply
   int cell_tt = 0, cell_tt_req = 0;       // target tiles per wavefront the target tile list was padded for; as requested (0 = auto)
-  float cell_lo[3] = {0.f, 0.f, 0.f}, cell_h = 0.f;
+  float cell_lo[3] = {0.f, 0.f, 0.f}, cell_hh[3] = {1.f, 1.f, 1.f};  // grid origin and cell sides per axis
   int cell_g[3] = {1, 1, 1};
   int64_t cell_n_tiles = 0, cell_m_tiles = 0;  // real tiles of 32 (targets / sources)
   float cloud_radius2 = INFINITY;          // squared half-diagonal of the clouds' bounding box

@@ -718,6 +718,44 @@ int cell_tiles(kmvp_ctx* c, const std::vector<unsigned>& keys, int mult, kmvp_ct
   return KMVP_OK;
 }
 
+// The grid of the cell paths: the bounding box (aux) divided, per axis, into the smallest number of equal cells
+// whose side stays within h_max (so boundary cells are as full as the others).  false: more than 1024 cells on an axis.
+bool cell_make_grid(const float* aux, int D, float h_max, CellGrid& grid) {
+  for (int a = 0; a < 3; ++a) {
+    grid.lo[a] = 0.f;
+    grid.g[a] = 1;
+    grid.h[a] = h_max;
+    grid.inv_h[a] = 1.f / h_max;
+  }
+  for (int a = 0; a < D; ++a) {
+    const float half = aux[FAST_AUX_HALF + a];
+    grid.lo[a] = aux[a] - half;
+    const double cells = std::max(1.0, std::ceil(2.0 * half / h_max));
+    if (!(cells <= CELL_MAX_GRID)) return false;
+    grid.g[a] = (int)cells;
+    if (half > 0.f) {
+      grid.h[a] = (float)(2.0 * half / cells);
+      grid.inv_h[a] = 1.f / grid.h[a];
+    }
+  }
+  return true;
+}
+void cell_store_grid(kmvp_ctx* c, const CellGrid& grid) {
+  for (int a = 0; a < 3; ++a) {
+    c->cell_lo[a] = grid.lo[a];
+    c->cell_g[a] = grid.g[a];
+    c->cell_hh[a] = grid.h[a];
+  }
+}
+void cell_load_grid(const kmvp_ctx* c, CellGrid& grid) {
+  for (int a = 0; a < 3; ++a) {
+    grid.lo[a] = c->cell_lo[a];
+    grid.g[a] = c->cell_g[a];
+    grid.h[a] = c->cell_hh[a];
+    grid.inv_h[a] = 1.f / c->cell_hh[a];
+  }
+}
+
 // tiles a cloud with these sorted cell keys occupies when every cell gets a multiple of `mult` tiles
 int64_t cell_count_tiles(const std::vector<unsigned>& keys, int mult) {
   const int64_t n = (int64_t)keys.size();
@@ -747,19 +785,7 @@ int cell_prepare(kmvp_ctx* c, int TT) {
   HIP_TRY(c, hipMemcpyAsync(aux, c->aux.p, sizeof(aux), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   CellGrid grid;
-  grid.h = std::sqrt(2.f * CELL_T_MAX / (float)D);  // |2 d.e| <= D h^2 / 2 <= CELL_T_MAX
-  grid.inv_h = 1.f / grid.h;
-  for (int a = 0; a < 3; ++a) {
-    grid.lo[a] = 0.f;
-    grid.g[a] = 1;
-  }
-  for (int a = 0; a < D; ++a) {
-    const float half = aux[FAST_AUX_HALF + a];
-    grid.lo[a] = aux[a] - half;
-    const double cells = std::floor(2.0 * half / grid.h) + 1.0;
-    if (!(cells <= CELL_MAX_GRID)) return KMVP_OK;
-    grid.g[a] = (int)cells;
-  }
+  if (!cell_make_grid(aux, D, (float)(std::sqrt(2.f * CELL_T_MAX / (float)D)), grid)) return KMVP_OK;  // |2 d.e| <= D h^2 / 2 <= the bound
   int rc;
   std::vector<unsigned> keys;
   if ((rc = cell_sort(c, c->y_raw.p, c->M, grid, c->cell_sperm, keys))) return rc;
@@ -776,11 +802,7 @@ int cell_prepare(kmvp_ctx* c, int TT) {
   }
   if ((rc = cell_tiles(c, keys, TT, c->cell_tgrp, &c->cell_n_tiles))) return rc;
   c->cell_tt = TT;
-  for (int a = 0; a < 3; ++a) {
-    c->cell_lo[a] = grid.lo[a];
-    c->cell_g[a] = grid.g[a];
-  }
-  c->cell_h = grid.h;
+  cell_store_grid(c, grid);
   c->cell_state = 1;
   c->packed_layout = -1;  // xs / rec are re-packed by whoever runs next
   return KMVP_OK;
@@ -806,12 +828,7 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   const int64_t m_stages = (c->cell_m_tiles + CELL_STAGE_TILES - 1) / CELL_STAGE_TILES;
   int rc;
   CellGrid grid;
-  for (int a = 0; a < 3; ++a) {
-    grid.lo[a] = c->cell_lo[a];
-    grid.g[a] = c->cell_g[a];
-  }
-  grid.h = c->cell_h;
-  grid.inv_h = 1.f / c->cell_h;
+  cell_load_grid(c, grid);
 
   int segments = choose_segments(c, tile_blocks, m_stages, NE, n_slots, CELL_STAGE_BYTES, small ? 1 : 4, small);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
@@ -892,19 +909,7 @@ int cell64_prepare(kmvp_ctx* c) {
   HIP_TRY(c, hipMemcpyAsync(aux, c->aux.p, sizeof(aux), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   CellGrid grid;
-  grid.h = (float)std::sqrt(2.0 * CELL64_T_MAX / (double)D);
-  grid.inv_h = 1.f / grid.h;
-  for (int a = 0; a < 3; ++a) {
-    grid.lo[a] = 0.f;
-    grid.g[a] = 1;
-  }
-  for (int a = 0; a < D; ++a) {
-    const float half = aux[FAST_AUX_HALF + a];
-    grid.lo[a] = aux[a] - half;
-    const double cells = std::floor(2.0 * half / grid.h) + 1.0;
-    if (!(cells <= CELL_MAX_GRID)) return KMVP_OK;
-    grid.g[a] = (int)cells;
-  }
+  if (!cell_make_grid(aux, D, (float)((float)std::sqrt(2.0 * CELL64_T_MAX / (double)D)), grid)) return KMVP_OK;  // |2 d.e| <= D h^2 / 2 <= the bound
   int rc;
   std::vector<unsigned> keys;
   if ((rc = cell_sort(c, c->y_raw.p, c->M, grid, c->cell_sperm, keys, &c->cell_skey))) return rc;
@@ -929,11 +934,7 @@ int cell64_prepare(kmvp_ctx* c) {
   if (!c->same_points && (rc = cell_sort(c, c->x_raw.p, c->N, grid, c->cell_tperm, keys))) return rc;
   if ((rc = cell_tiles(c, keys, 1, c->cell_tgrp, &c->cell_n_tiles, CELL64_TILE))) return rc;
   c->cell_tt = 1;
-  for (int a = 0; a < 3; ++a) {
-    c->cell_lo[a] = grid.lo[a];
-    c->cell_g[a] = grid.g[a];
-  }
-  c->cell_h = grid.h;
+  cell_store_grid(c, grid);
   c->cell_state = 1;
   c->packed_layout = -1;
   return KMVP_OK;
@@ -948,12 +949,7 @@ int run_product_cell64(kmvp_ctx* c, int sig) {
   const int n_scells = (int)c->cell_m_tiles;
   int rc;
   CellGrid grid;
-  for (int a = 0; a < 3; ++a) {
-    grid.lo[a] = c->cell_lo[a];
-    grid.g[a] = c->cell_g[a];
-  }
-  grid.h = c->cell_h;
-  grid.inv_h = 1.f / c->cell_h;
+  cell_load_grid(c, grid);
   // segments of whole source cells: enough workgroups for a few rounds of the chip
   int64_t seg = c->opt_segments > 0 ? c->opt_segments : (8192 + tile_blocks - 1) / tile_blocks;
   seg = std::max<int64_t>(1, std::min<int64_t>(seg, n_scells));

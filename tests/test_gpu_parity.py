@@ -208,8 +208,9 @@ def test_cell64_kernel_at_scale_and_in_the_solver():
     got, extra = run_plugin(dict(kernel="gaussian", D=2), y2, x2, b2, np.float64, fast_sqdists="cells")
     assert extra["device_kernel"] == "cell64_kernel"
     assert rel_err(got[rows], want) <= TOL64, rel_err(got[rows], want)
-    # the solver on that operator (x := K b0, then solve K b = x)
-    m = 40000
+    # the solver on that operator (x := K b0, then solve K b = x); 80000 points fill the 128-target tiles of the
+    # 216 cells (370 per cell), 40000 would leave 38 % of the slots empty and stay with the difference form
+    m = 80000
     ys = rs.rand(m, 3)
     b0 = rs.randn(m, 1)
     algo = MI355XProduct(kernel="gaussian", dimension=3, precision=np.float64)
