@@ -25,6 +25,23 @@ def shard_range(M, rank, world):
 CELL_T_MAX = 0.016  # kmvp_cell.hpp: bound on |2 d.e| that fixes the cell side
 
 
+def cell_indices(p):
+    """Integer cell coordinates of float32 points on libkmvp's grid (kmvp_product.hip:cell_make_grid): per axis
+    the bounding box is divided into the smallest number of equal cells of side <= sqrt(2 CELL_T_MAX / D).
+    ``None`` when an axis would need more than 1024 cells."""
+    import numpy as np
+
+    h_max = np.sqrt(2.0 * CELL_T_MAX / p.shape[1])
+    lo = p.min(axis=0).astype(np.float64)
+    extent = p.max(axis=0).astype(np.float64) - lo
+    counts = np.maximum(1.0, np.ceil(extent / h_max))
+    if counts.max() > 1024:
+        return None
+    h = np.where(extent > 0, extent / counts, h_max)
+    cells = np.floor((p.astype(np.float64) - lo) / h).astype(np.int64)
+    return np.minimum(cells, counts.astype(np.int64) - 1)
+
+
 def spatial_order(points):
     """Permutation that lists the points cell by cell of a regular grid (the grid of libkmvp's
     ``cell_kernel``: side sqrt(2 * CELL_T_MAX / D)), or ``None`` when that grid does not apply (D > 3,
@@ -41,9 +58,8 @@ def spatial_order(points):
     p = np.asarray(points, dtype=np.float32)
     if p.ndim != 2 or p.shape[0] == 0 or p.shape[1] > 3 or not np.isfinite(p).all():
         return None
-    h = np.float32(np.sqrt(2.0 * CELL_T_MAX / p.shape[1]))
-    cells = np.floor((p - p.min(axis=0)) / h).astype(np.int64)
-    if cells.max() >= 1024:
+    cells = cell_indices(p)
+    if cells is None:
         return None
     key = np.zeros(p.shape[0], dtype=np.int64)
     for a in range(p.shape[1]):

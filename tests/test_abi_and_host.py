@@ -139,8 +139,8 @@ def test_spatial_order_keeps_cells_together_and_sums_unchanged():
     assert float(re.search(r"CELL_T_MAX = ([0-9.]+)f", header).group(1)) == sharding.CELL_T_MAX  # one grid on both sides
     order = sharding.spatial_order(y)
     assert sorted(order.tolist()) == list(range(4000))
-    h = np.sqrt(2 * sharding.CELL_T_MAX / 3)
-    cells = np.floor((y.astype(np.float32) - y.astype(np.float32).min(axis=0)) / np.float32(h)).astype(int)
+    cells = sharding.cell_indices(y.astype(np.float32))
+    assert cells.max(axis=0).tolist() == [9, 9, 9]  # unit cube: ten cells of side 0.1 <= 0.103 per axis
     keys = cells[:, 0] + 1024 * cells[:, 1] + 1024 * 1024 * cells[:, 2]
     assert (np.diff(keys[order]) >= 0).all()
     world = 4
