@@ -1,0 +1,25 @@
+"""Gaussian at the config-4 shape (1e7 targets x one of 8 source shards, float32): the cell path at scale."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from kernel_matrix_benchmarks_amd import _lib, sharding
+import c_oracle
+n = 10_000_000
+rs = np.random.RandomState(n + 3)
+y = rs.rand(n, 3).astype(np.float32); b = rs.randn(n, 1).astype(np.float32)
+order = sharding.spatial_order(y)
+lo, hi = sharding.shard_range(n, 0, 8)
+ys, bs = y[order][lo:hi], b[order][lo:hi]
+ctx = _lib.Context(0)
+ctx.set_points(np.ascontiguousarray(ys), y, _lib.KMVP_F32, j_offset=lo, M_total=n)
+ctx.set_signal(np.ascontiguousarray(bs))
+for _ in range(3):
+    t0 = time.perf_counter(); ctx.run("gaussian", False); wall = time.perf_counter() - t0
+out = ctx.get_result(n, 1)
+rows = rs.choice(n, size=256, replace=False)
+want = c_oracle.product(kernel="gaussian", source_points=ys.astype(np.float64), target_points=y[rows].astype(np.float64),
+                        source_signal=bs.astype(np.float64)) if hasattr(c_oracle, "product") else None
+err = np.max(np.abs(out[rows] - want)) / np.max(np.abs(want))
+print(f"{ctx.last_kernel_name}: N={n} x M={hi-lo}: kernel {ctx.last_kernel_ms:.1f} ms wall {wall*1e3:.1f} ms  {n*(hi-lo)/(ctx.last_kernel_ms*1e-3):.3e} pairs/s  rel_err {err:.2e}  device {ctx.device_bytes/1e6:.0f} MB")
+ctx.close()
