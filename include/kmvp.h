@@ -149,8 +149,8 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  *                      3 = always the cell form (cell_kernel: Gaussian, D <= 3): exp() is range-reduced
  *                          by the cells of a regular grid, exp(-|x-y|^2) = U_i(S) W_j(T) exp(2 d.e),
  *                          and the remainder polynomial 1 + t + t^2/2 of t = 2 d.e (|t| <= 0.016)
- *                          comes out of one bf16 MFMA per 32 x 32 pairs; float64 (cell64_kernel, plain
- *                          products with E == 1): the degree-8 polynomial on the VALU;
+ *                          comes out of one bf16 MFMA per 32 x 32 pairs; float64 (cell64_kernel,
+ *                          E == 1): the degree-7 polynomial on the VALU;
  *                      0 = never (difference form, bruteforce.py:53-54);
  *                      -1 = auto (default): the cheapest form that is as accurate as the
  *                          difference form -- for the Gaussian on clouds of small scaled radius

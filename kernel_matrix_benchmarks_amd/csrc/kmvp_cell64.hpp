@@ -38,7 +38,7 @@ struct Cell64Args {
   const double* srec;     // sources [m + 64][4] in cell order: 2 e_x, 2 e_y, 2 e_z, b (64 zero records behind the last)
   const int* scell;       // source cells [n_scells][2]: first record, count
   const double* scentre;  // source cells [n_scells][4]: c_x, c_y, c_z, 0
-  double* part;           // partial sums [segments][n_slots]
+  double* part;           // partial sums [segments][NE][n_slots], NE = 2 for normalised rows
   int64_t n_slots;
   int n_scells;
   int seg_cells;          // source cells per segment
@@ -60,22 +60,26 @@ __device__ __forceinline__ double cell64_exp(double t) {
   return fma(p, t, 1.0);
 }
 
-// one source against the lane's targets
-__device__ __forceinline__ void cell64_pair(const double (&d)[CELL64_TPL][3], const f64x4 rec, double wb,
-                                            double (&acc)[CELL64_TPL]) {
+// one source against the lane's targets (NE = 2: w[0] = W_j b_j for the numerator, w[1] = W_j for the denominator)
+template <int NE>
+__device__ __forceinline__ void cell64_pair(const double (&d)[CELL64_TPL][3], const f64x4 rec, const double (&w)[NE],
+                                            double (&acc)[CELL64_TPL][NE]) {
 #pragma unroll
   for (int k = 0; k < CELL64_TPL; ++k) {
     const double t = fma(d[k][0], rec[0], fma(d[k][1], rec[1], d[k][2] * rec[2]));
-    acc[k] = fma(cell64_exp(t), wb, acc[k]);
+    const double p = cell64_exp(t);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[k][e] = fma(p, w[e], acc[k][e]);
   }
 }
 
-// SIG: SIG_PRODUCT only (density = product with b = 1, set by the packer); a template so that the header can be
-// included by more than one translation unit
+// SIG: SIG_PRODUCT (density = product with b = 1, set by the packer) or SIG_NORM (numerator and denominator in one
+// sweep: a second sum with W_j alone)
 template <int SIG>
 __global__ void __launch_bounds__(BLOCK_THREADS) cell64_kernel(const Cell64Args a) {
   __shared__ double exp_tab[64];
-  __shared__ double wsh[WAVES_PER_BLOCK][64];  // W_j b_j of the wave's current 64 sources (broadcast reads)
+  constexpr int NE = SIG == SIG_NORM ? 2 : 1;
+  __shared__ double wsh[WAVES_PER_BLOCK][64][NE];  // W_j b_j (and W_j) of the wave's current 64 sources (broadcast reads)
   if (threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
   __syncthreads();
   int tb, seg;
@@ -84,14 +88,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell64_kernel(const Cell64Args 
   const int wave = threadIdx.x >> 6;
   const int64_t tile = (int64_t)tb * WAVES_PER_BLOCK + wave;
   const f64x4 ct = *reinterpret_cast<const f64x4*>(a.tmeta + tile * 4);  // wave-uniform
-  double d[CELL64_TPL][3], acc[CELL64_TPL];
+  double d[CELL64_TPL][3], acc[CELL64_TPL][NE];
 #pragma unroll
   for (int k = 0; k < CELL64_TPL; ++k) {
     const f64x4 dv = *reinterpret_cast<const f64x4*>(a.xd + (tile * CELL64_TILE + 64 * k + lane) * 4);
     d[k][0] = dv[0];
     d[k][1] = dv[1];
     d[k][2] = dv[2];
-    acc[k] = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[k][e] = 0.0;
   }
 
   const int c_begin = seg * a.seg_cells;
@@ -101,9 +106,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell64_kernel(const Cell64Args 
     const int count = __builtin_amdgcn_readfirstlane(a.scell[2 * sc + 1]);
     const f64x4 cs = *reinterpret_cast<const f64x4*>(a.scentre + (int64_t)sc * 4);
     const double Dx = ct[0] - cs[0], Dy = ct[1] - cs[1], Dz = ct[2] - cs[2];
-    double accc[CELL64_TPL];
+    double accc[CELL64_TPL][NE];
 #pragma unroll
-    for (int k = 0; k < CELL64_TPL; ++k) accc[k] = 0.0;
+    for (int k = 0; k < CELL64_TPL; ++k)
+#pragma unroll
+      for (int e = 0; e < NE; ++e) accc[k][e] = 0.0;
     for (int base = 0; base < count; base += 64) {
       const int nj = min(64, count - base);
       // W_j b_j with the source on the lane (records behind the cell's last one belong to the next
@@ -111,9 +118,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell64_kernel(const Cell64Args 
       const f64x4 mine = *reinterpret_cast<const f64x4*>(a.srec + ((int64_t)first + base + lane) * 4);
       // e.(2D - e) with e = rec/2:  rec.(D - rec/4)
       const double arg = fma(mine[0], fma(mine[0], -0.25, Dx), fma(mine[1], fma(mine[1], -0.25, Dy), mine[2] * fma(mine[2], -0.25, Dz)));
-      wsh[wave][lane] = lane < nj ? kexp_neg_f64(-arg, exp_tab) * mine[3] : 0.0;
+      const double wj = lane < nj ? kexp_neg_f64(-arg, exp_tab) : 0.0;
+      wsh[wave][lane][0] = wj * mine[3];
+      if constexpr (NE == 2) wsh[wave][lane][1] = wj;
       __builtin_amdgcn_wave_barrier();
-      const double* wbp = &wsh[wave][0];
+      const double (*wbp)[NE] = wsh[wave];
       const double* rec0 = a.srec + ((int64_t)first + base) * 4;  // wave-uniform
       // records two at a time through the scalar cache, the next pair requested before this one is used
       int j = 0;
@@ -125,13 +134,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell64_kernel(const Cell64Args 
             n0 = *reinterpret_cast<const f64x4*>(rec0 + (j + 2) * 4);
             n1 = *reinterpret_cast<const f64x4*>(rec0 + (j + 3) * 4);
           }
-          cell64_pair(d, r0, wbp[j + 0], accc);
-          cell64_pair(d, r1, wbp[j + 1], accc);
+          cell64_pair<NE>(d, r0, wbp[j + 0], accc);
+          cell64_pair<NE>(d, r1, wbp[j + 1], accc);
         }
       }
       if (j < nj) {
         const f64x4 r0 = *reinterpret_cast<const f64x4*>(rec0 + j * 4);
-        cell64_pair(d, r0, wbp[j], accc);
+        cell64_pair<NE>(d, r0, wbp[j], accc);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -139,13 +148,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell64_kernel(const Cell64Args 
     for (int k = 0; k < CELL64_TPL; ++k) {
       const double ux = d[k][0] + Dx, uy = d[k][1] + Dy, uz = d[k][2] + Dz;
       const double U = kexp_neg_f64(fma(ux, ux, fma(uy, uy, uz * uz)), exp_tab);
-      acc[k] = fma(U, accc[k], acc[k]);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) acc[k][e] = fma(U, accc[k][e], acc[k][e]);
     }
   }
 #pragma unroll
-  for (int k = 0; k < CELL64_TPL; ++k) a.part[(int64_t)seg * a.n_slots + tile * CELL64_TILE + 64 * k + lane] = acc[k];
+  for (int k = 0; k < CELL64_TPL; ++k)
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      a.part[((int64_t)seg * NE + e) * a.n_slots + tile * CELL64_TILE + 64 * k + lane] = acc[k][e];
 }
 
-hipError_t launch_cell64_gaussian(const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name);
+hipError_t launch_cell64_gaussian(int sig, const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name);
 
 }  // namespace kmvp

@@ -28,9 +28,10 @@ hipError_t launch_cell_gaussian(int sig, int TT, const CellArgs& args, dim3 grid
   }
 }
 
-hipError_t launch_cell64_gaussian(const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name) {
+hipError_t launch_cell64_gaussian(int sig, const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name) {
   if (kernel_name) *kernel_name = "cell64_kernel";
-  hipLaunchKernelGGL((cell64_kernel<SIG_PRODUCT>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+  if (sig == SIG_NORM) hipLaunchKernelGGL((cell64_kernel<SIG_NORM>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+  else hipLaunchKernelGGL((cell64_kernel<SIG_PRODUCT>), grid, dim3(BLOCK_THREADS), 0, stream, args);
   return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ struct CellArgs;
 hipError_t launch_cell_gaussian(int sig, int TT, const CellArgs& args, dim3 grid, hipStream_t stream,
                                 const char** kernel_name);
 struct Cell64Args;
-hipError_t launch_cell64_gaussian(const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name);
+hipError_t launch_cell64_gaussian(int sig, const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name);
 // kmvp_sort.hip: hipcub radix sort of (key, value) pairs; tmp == nullptr queries the scratch size
 hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const unsigned* keys_in, unsigned* keys_out,
                           const int* vals_in, int* vals_out, int64_t n, hipStream_t stream);

@@ -942,6 +942,7 @@ int cell64_prepare(kmvp_ctx* c) {
 
 int run_product_cell64(kmvp_ctx* c, int sig) {
   const int D = c->D;
+  const int NE = sig == SIG_NORM ? 2 : 1;
   const int64_t N = c->N, M = c->M;
   const int64_t n_tiles = round_up(c->cell_n_tiles, WAVES_PER_BLOCK);
   const int64_t n_slots = n_tiles * CELL64_TILE;
@@ -985,7 +986,7 @@ int run_product_cell64(kmvp_ctx* c, int sig) {
   c->packed_layout = LAYOUT_CELL64;
   c->packed_T = 1;
 
-  if ((rc = ensure(c, c->part, (size_t)segments * n_slots * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->part, (size_t)segments * NE * n_slots * sizeof(double)))) return rc;
   Cell64Args a;
   a.xd = (const double*)c->xs.p;
   a.tmeta = (const double*)c->cell_tmeta.p;
@@ -1000,17 +1001,17 @@ int run_product_cell64(kmvp_ctx* c, int sig) {
   a.tile_blocks = (int)tile_blocks;
   const dim3 grid_dim((unsigned)(tile_blocks * segments));
   HIP_TRY(c, mark(c, 0));
-  HIP_TRY(c, launch_cell64_gaussian(a, grid_dim, c->stream, &c->last_kernel_name));
+  HIP_TRY(c, launch_cell64_gaussian(sig, a, grid_dim, c->stream, &c->last_kernel_name));
   HIP_TRY(c, mark(c, 1));
 
-  if ((rc = ensure(c, c->sums, (size_t)N * sizeof(double)))) return rc;
-  if ((rc = ensure(c, c->cell_sums, (size_t)n_slots * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(n_slots)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->cell_sums.p, n_slots, segments);
-  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for(N)), dim3(256), 0, c->stream,
-                     (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, 1);
+  if ((rc = ensure(c, c->sums, (size_t)NE * N * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->cell_sums, (size_t)NE * n_slots * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for((int64_t)NE * n_slots)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->cell_sums.p, (int64_t)NE * n_slots, segments);
+  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream,
+                     (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, NE);
   HIP_TRY(c, hipGetLastError());
-  return finish_product(c, N, N, N, 1, sig);
+  return finish_product(c, (int64_t)NE * N, N, N, 1, sig);
 }
 
 // bf16 MFMA path (kmvp_mfma.hpp): host arrays are float32, points and signal are packed
@@ -1231,7 +1232,7 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     if (c->opt_fast == 1 || (c->opt_fast < 0 && global_ok)) return run_product_fast(c, kernel, sig);
     if (centred_ok && (c->opt_fast == 2 || c->opt_fast < 0)) return run_product_cfast(c, kernel, sig);
   }
-  if (c->dtype == KMVP_F64 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && (c->density || c->E == 1) && sig != SIG_NORM &&
+  if (c->dtype == KMVP_F64 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && (c->density || c->E == 1) &&
       c->centre_ver == c->points_ver &&
       (c->opt_fast == 3 || (c->opt_fast < 0 && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
     // float64 cell form (kmvp_cell64.hpp): 12 fp64 instructions per pair instead of ~23
