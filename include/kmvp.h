@@ -117,8 +117,10 @@ int kmvp_get_result(kmvp_ctx* ctx, double* out, int64_t out_len);
  * uses a dense lstsq; parity is judged on the residual.
  *   a: (M,E) in the ctx dtype.  rtol: target ||K b - a|| / ||a|| (per column).
  *   out_b (M,E) float64 receives the iterate; *iters / *resid the iteration
- *   count and the worst final relative residual.  Returns KMVP_E_NOT_CONVERGED
- *   (with out_b still written) when maxit is reached. */
+ *   count and the worst final TRUE relative residual (from one more product).  Returns KMVP_OK
+ *   only if that residual is finite and <= 1.5 rtol (the iteration stops on the recurrence residual;
+ *   where the two drift apart it is restarted from the true one); otherwise KMVP_E_NOT_CONVERGED with
+ *   out_b still written -- also for a non-finite operator or right-hand side. */
 int kmvp_gaussian_cg_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, int maxit,
                            double* out_b, int* iters, double* resid);
 int kmvp_absexp_cg_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, int maxit,
@@ -134,6 +136,12 @@ int kmvp_invdist_minres_solve(kmvp_ctx* ctx, const void* a, int E, double rtol, 
 #define KMVP_UNIQUE_ID_BYTES 128
 int kmvp_comm_get_unique_id(void* id128);
 int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
+/* What the attached RCCL communicator ITSELF reports (ncclCommCount / ncclCommUserRank; kmvp_comm_init
+ * fails with KMVP_E_COMM when they differ from what it was asked for).  1 / 0 without a communicator.
+ * bench.py prints the count as "rccl_ranks" so that a multi-GPU line shows the collective really spanned
+ * N ranks. */
+int kmvp_comm_world(const kmvp_ctx* ctx);
+int kmvp_comm_rank(const kmvp_ctx* ctx);
 
 /* BaseAlgorithm.set_query_arguments (base.py:40-42): tuning knobs, all optional.
  *   "feed"             -1 = auto (default), 0 = scalar-cache source stream, 1 = LDS-staged tiles
@@ -158,6 +166,9 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  *                          <= 30 %), else 1; else 2 where it applies
  *   "same_points_global" 1 when the targets passed to kmvp_set_points are the unsharded
  *                      sources (sharded same_points): enables form 2 for inverse-distance
+ *   "partial_shard"    1: a source slice (M < M_total) may be run WITHOUT a multi-rank communicator and
+ *                      returns that shard's partial sums (the caller adds the shards up); default 0: such
+ *                      a call fails with KMVP_E_INVALID instead of passing partial sums off as the product
  *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4, 8
  *                      (clamped to what is instantiated: fast_kernel 4 up to D = 7, 2 up to D = 23,
  *                      1 beyond; cfast_kernel 4; cell_kernel 8) */
@@ -170,6 +181,8 @@ int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);
 int64_t kmvp_device_bytes(const kmvp_ctx* ctx);
 double kmvp_last_kernel_ms(const kmvp_ctx* ctx);
 double kmvp_last_total_ms(const kmvp_ctx* ctx);
+/*   kmvp_last_allreduce_ms  the RCCL all-reduce of the (N,E[+1]) sums alone (0 without a communicator) */
+double kmvp_last_allreduce_ms(const kmvp_ctx* ctx);
 /* name of the pair-loop kernel the last compute call launched (for rocprof matching) */
 const char* kmvp_last_kernel_name(const kmvp_ctx* ctx);
 

@@ -44,6 +44,9 @@ SYMBOLS = [
                                              _c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
     ("kmvp_comm_get_unique_id", _c.c_int, [_c.c_void_p]),
     ("kmvp_comm_init", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
+    ("kmvp_comm_world", _c.c_int, [_c.c_void_p]),
+    ("kmvp_comm_rank", _c.c_int, [_c.c_void_p]),
+    ("kmvp_last_allreduce_ms", _c.c_double, [_c.c_void_p]),
     ("kmvp_set_option", _c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_int64]),
     ("kmvp_device_bytes", _c.c_int64, [_c.c_void_p]),
     ("kmvp_last_kernel_ms", _c.c_double, [_c.c_void_p]),
@@ -101,6 +104,7 @@ class Context:
             msg = self._lib.kmvp_last_error(None)
             raise KmvpError(status.value, msg.decode() if msg else "kmvp_create failed")
         self.device = int(device)
+        self.comm_world = 0  # ranks of the communicator attached to THIS context (0: none)
 
     def _check(self, rc):
         if rc != 0:
@@ -121,6 +125,9 @@ class Context:
     def set_points(self, y, x, dtype_code_, j_offset=0, M_total=None):
         M, D = y.shape
         N = M if x is None else x.shape[0]
+        if x is not None and x.shape[1] != D:
+            raise ValueError(f"target points have {x.shape[1]} coordinates, source points {D}")
+        self.M, self.N, self.D = M, N, D
         self._check(self._lib.kmvp_set_points(
             self._ctx, y.ctypes.data, M, None if x is None else x.ctypes.data, N, D, dtype_code_,
             int(j_offset), int(M if M_total is None else M_total)))
@@ -132,6 +139,10 @@ class Context:
         if b is None:
             self._check(self._lib.kmvp_set_signal(self._ctx, None, 1))
         else:
+            # the library copies M * E elements from the pointer: a shorter array must never reach it
+            if b.ndim != 2 or b.shape[0] != getattr(self, "M", b.shape[0]):
+                raise ValueError(f"source_signal has shape {b.shape}, expected ({getattr(self, 'M', '?')}, E): one row per "
+                                 "source point")
             self._check(self._lib.kmvp_set_signal(self._ctx, b.ctypes.data, b.shape[1]))
 
     def run(self, kernel, normalize_rows):
@@ -151,6 +162,9 @@ class Context:
         return out
 
     def cg_solve(self, kernel, a, rtol, maxit):
+        if a.ndim != 2 or a.shape[0] != getattr(self, "N", a.shape[0]):
+            # the Krylov vectors have one row per point (all points are targets); the library reads N * E elements
+            raise ValueError(f"target_signal has shape {a.shape}, the point cloud has {self.N} points")
         entry = {
             "gaussian": self._lib.kmvp_gaussian_cg_solve,
             "absolute-exponential": self._lib.kmvp_absexp_cg_solve,
@@ -171,6 +185,16 @@ class Context:
     def comm_init(self, unique_id, rank, world):
         buf = (ctypes.c_char * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._check(self._lib.kmvp_comm_init(self._ctx, buf, int(rank), int(world)))
+        self.comm_world = int(world)  # attachment is recorded on the context itself (sharding.Communicator.attach)
+
+    @property
+    def rccl_ranks(self):
+        """Ranks the attached RCCL communicator itself reports (1 without one)."""
+        return int(self._lib.kmvp_comm_world(self._ctx))
+
+    @property
+    def last_allreduce_ms(self):
+        return float(self._lib.kmvp_last_allreduce_ms(self._ctx))
 
     def set_option(self, key, value):
         self._check(self._lib.kmvp_set_option(self._ctx, key.encode(), int(value)))

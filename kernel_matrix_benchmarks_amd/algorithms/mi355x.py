@@ -8,8 +8,10 @@ of ``include/kmvp.h``.  There is no CPU path: without the library or a GPU the
 calls raise.
 
 Differences a user should know about
- * ``fit()`` has nothing to pre-compute (no N x M matrix exists); compare on
-   build_time + query_time, which is the harness' default axis (plot.py:128).
+ * ``fit()`` never forms the N x M matrix; it builds what the points alone determine
+   (``kmvp_fit``: grid, cell order and tile lists of the Gaussian cell kernels, a few ms
+   at 1e6 points; nothing for the other kernels).  Compare on build_time + query_time,
+   which is the harness' default axis (plot.py:128).
  * The HIP context is created in ``prepare_data`` -- never at import or
    construction -- because the harness imports plugins in its parent process
    before forking the worker (main.py:262-308).
@@ -118,6 +120,9 @@ class MI355XProduct(BaseProduct):
         b = np.ascontiguousarray(source_signal, dtype=self._host_dtype)
         if b.ndim == 1:
             b = b.reshape(-1, 1)
+        if b.ndim != 2 or b.shape[0] != self.M:
+            # the reference fails in its matmul (bruteforce.py:150); here a short array would be read past its end
+            raise ValueError(f"source_signal has shape {b.shape}, expected ({self.M}, E)")
         self.E = b.shape[1]
         lo, hi = self._shard
         if self._order is not None:
@@ -172,6 +177,9 @@ class MI355XProduct(BaseProduct):
             "device_total_ms": self._ctx.last_total_ms,
             "device_kernel": self._ctx.last_kernel_name,
             "n_gpus": 1 if self.comm is None else self.comm.world,
+            # what RCCL itself saw, and the all-reduce's share of device_total_ms (0 on one GPU)
+            "rccl_ranks": self._ctx.rccl_ranks,
+            "allreduce_ms": self._ctx.last_allreduce_ms,
         }
 
     def done(self):
@@ -238,6 +246,8 @@ class MI355XSolver(BaseSolver):
     def prepare_query(self, *, target_signal):
         a = np.ascontiguousarray(target_signal, dtype=self._host_dtype)
         self._a = a.reshape(-1, 1) if a.ndim == 1 else a
+        if self._a.ndim != 2 or self._a.shape[0] != self.M:
+            raise ValueError(f"target_signal has shape {a.shape}, expected ({self.M}, E)")
 
     def set_query_arguments(self, rtol=None, maxit=None):
         if rtol is not None:
@@ -253,8 +263,12 @@ class MI355XSolver(BaseSolver):
         return 0.0 if self._ctx is None else self._ctx.device_bytes / 1024
 
     def get_additional(self):
-        return {"cg_iterations": self.iterations, "cg_relative_residual": self.residual,
-                "cg_converged": bool(self.converged), "n_gpus": 1 if self.comm is None else self.comm.world}
+        extra = {"cg_iterations": self.iterations, "cg_relative_residual": self.residual,
+                 "cg_converged": bool(self.converged), "n_gpus": 1 if self.comm is None else self.comm.world}
+        if self._ctx is not None:
+            extra["device_kernel"] = self._ctx.last_kernel_name  # the operator's pair-loop kernel
+            extra["rccl_ranks"] = self._ctx.rccl_ranks
+        return extra
 
     def done(self):
         if self._ctx is not None:

@@ -72,7 +72,7 @@ kmvp_ctx* kmvp_create(int device, int* status) {
   c->device = device;
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
+  for (int i = 0; ok && i < 5; ++i) ok = hipEventCreate(&c->ev[i]) == hipSuccess;
   if (!ok) {
     fail(nullptr, KMVP_E_DEVICE, "cannot create stream/events on the device");
     if (status) *status = KMVP_E_DEVICE;
@@ -92,7 +92,7 @@ void kmvp_destroy(kmvp_ctx* c) {
                     &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg,
                     &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre})
     release(*b);
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 5; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -222,10 +222,31 @@ int kmvp_comm_init(kmvp_ctx* c, const void* id128, int rank, int world) {
     c->comm = nullptr;
     return fail(c, KMVP_E_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
   }
+  // what RCCL itself believes: a communicator whose size or rank differs from what the caller asked
+  // for would hand back partial sums as results (or hang in the first all-reduce)
+  int count = -1, user_rank = -1, dev = -1;
+  ncclResult_t r1 = g_rccl.CommCount(c->comm, &count);
+  ncclResult_t r2 = g_rccl.CommUserRank(c->comm, &user_rank);
+  (void)g_rccl.CommCuDevice(c->comm, &dev);  // reported in the message only
+  if (r1 != ncclSuccess || r2 != ncclSuccess || count != world || user_rank != rank) {
+    g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->comm_count = 1;
+    c->rank = 0;
+    c->world = 1;
+    return fail(c, KMVP_E_COMM, "RCCL communicator mismatch: asked for rank " + std::to_string(rank) + " of " +
+                                    std::to_string(world) + " on device " + std::to_string(c->device) + ", RCCL reports rank " +
+                                    std::to_string(user_rank) + " of " + std::to_string(count) + " on device " +
+                                    std::to_string(dev));
+  }
+  c->comm_count = count;
   c->rank = rank;
   c->world = world;
   return KMVP_OK;
 }
+
+int kmvp_comm_world(const kmvp_ctx* c) { return (c && c->comm) ? c->comm_count : 1; }
+int kmvp_comm_rank(const kmvp_ctx* c) { return (c && c->comm) ? c->rank : 0; }
 
 int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return KMVP_E_INVALID;
@@ -245,6 +266,8 @@ int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
     c->opt_fast = (int)value;
   } else if (k == "same_points_global") {
     c->opt_same_global = value != 0;
+  } else if (k == "partial_shard") {
+    c->opt_partial = value != 0;
   } else if (k == "fast_tiles") {
     if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
       return fail(c, KMVP_E_INVALID, "fast_tiles must be 0 (auto), 1, 2, 4 or 8");
@@ -269,6 +292,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
 }
 double kmvp_last_kernel_ms(const kmvp_ctx* c) { return c ? c->last_kernel_ms : 0.0; }
 double kmvp_last_total_ms(const kmvp_ctx* c) { return c ? c->last_total_ms : 0.0; }
+double kmvp_last_allreduce_ms(const kmvp_ctx* c) { return c ? c->last_allreduce_ms : 0.0; }
 const char* kmvp_last_kernel_name(const kmvp_ctx* c) { return c ? c->last_kernel_name : ""; }
 
 }  // extern "C"

@@ -37,6 +37,9 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                             hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error, path;
   bool load() {
@@ -76,7 +79,11 @@ struct Rccl {
     AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
     CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
     GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
-    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString) {
+    CommCount = (decltype(CommCount))dlsym(handle, "ncclCommCount");
+    CommUserRank = (decltype(CommUserRank))dlsym(handle, "ncclCommUserRank");
+    CommCuDevice = (decltype(CommCuDevice))dlsym(handle, "ncclCommCuDevice");
+    if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy || !GetErrorString || !CommCount || !CommUserRank ||
+        !CommCuDevice) {
       error = "librccl lacks an expected symbol";
       return false;
     }
@@ -90,7 +97,7 @@ struct kmvp_ctx {
   using DevBuf = kmvp::DevBuf;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // product start, pair loop end, end; all-reduce start, end
   std::string err;
 
   // problem
@@ -128,6 +135,7 @@ struct kmvp_ctx {
   int opt_feed = -1, opt_T = 0, opt_segments = 0, opt_chunk = 512;
   int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always, 2 always the centred form, 3 always the cell form
   int opt_same_global = 0;                // the targets ARE the (unsharded) sources although x was passed explicitly
+  int opt_partial = 0;                    // a source slice (M < M_total) may run WITHOUT a communicator: the caller sums the shards
   uint64_t perm_ver = 0;                  // points version the Morton order belongs to
   uint64_t cell_ver = 0;                  // points version the cell structures belong to
   int cell_state = 0;                     // for cell_ver: 0 not examined, 1 built, -1 the path does not apply
@@ -142,7 +150,8 @@ struct kmvp_ctx {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
 
-  float last_kernel_ms = 0.f, last_total_ms = 0.f;
+  int comm_count = 1;                      // ranks the RCCL communicator itself reports (ncclCommCount)
+  float last_kernel_ms = 0.f, last_total_ms = 0.f, last_allreduce_ms = 0.f;
   const char* last_kernel_name = "";
 };
 

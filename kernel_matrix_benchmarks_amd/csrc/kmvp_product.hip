@@ -157,6 +157,10 @@ __global__ void fill_kernel(double* p, int64_t n, double v) {
 }
 
 
+// Timing marks of a synchronous product; an asynchronous one (solver iteration, possibly inside a
+// stream capture) records nothing.
+inline hipError_t mark(kmvp_ctx* c, int i) { return c->async_product ? hipSuccess : hipEventRecord(c->ev[i], c->stream); }
+
 // Common tail of every path, after the path's own reduction has left sums[column][n_pad]
 // (fp64) in c->sums: one RCCL all-reduce over the source shards when a communicator is
 // attached, normalisation / transposition into (N,E), event bookkeeping, and the stream
@@ -173,10 +177,12 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
     hipLaunchKernelGGL(unpad_kernel, dim3(blocks_for(NE * N)), dim3(256), 0, c->stream, sums, (double*)c->xchg.p,
                        N, n_pad, NE);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, mark(c, 3));
     ncclResult_t r = g_rccl.AllReduce(c->xchg.p, c->xchg.p, (size_t)(NE * N), ncclFloat64, ncclSum, c->comm,
                                       c->stream);
     if (r != ncclSuccess)
       return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    HIP_TRY(c, mark(c, 4));
     sums = (const double*)c->xchg.p;
     n_pad = N;
   }
@@ -191,12 +197,11 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
+  c->last_allreduce_ms = 0.f;
+  if (c->comm) HIP_TRY(c, hipEventElapsedTime(&c->last_allreduce_ms, c->ev[3], c->ev[4]));
   return KMVP_OK;
 }
 
-// Timing marks of a synchronous product; an asynchronous one (solver iteration, possibly inside a
-// stream capture) records nothing.
-inline hipError_t mark(kmvp_ctx* c, int i) { return c->async_product ? hipSuccess : hipEventRecord(c->ev[i], c->stream); }
 
 // Epilogue of the paths with fp64 partials [segment][column][n_pad] in c->part.  Without a
 // communicator one fused launch does it; with one, the segments are summed into c->sums first and
@@ -222,6 +227,7 @@ int reduce_and_finish(kmvp_ctx* c, int segments, int NE, int64_t N, int64_t n_pa
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
+  c->last_allreduce_ms = 0.f;
   return KMVP_OK;
 }
 
@@ -1159,6 +1165,12 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
   if (!c->have_signal) return fail(c, KMVP_E_INVALID, "kmvp_set_signal has not been called");
   HIP_TRY(c, hipSetDevice(c->device));
+  if (c->M < c->m_total && !(c->comm && c->world > 1) && !c->opt_partial)
+    // a slice of the sources and nobody to sum the shards with: the result would be this rank's partial
+    // sums passed off as the product
+    return fail(c, KMVP_E_INVALID,
+                "the sources are a shard (M < M_total) but no multi-rank communicator is attached: call kmvp_comm_init, "
+                "or set option partial_shard = 1 to get this shard's partial sums on purpose");
   if (c->M == 0 && c->N > 0 && c->comm && c->world > 1) {
     // a rank whose source slice is empty still owes the other ranks its (zero) share of the sums
     const int sig0 = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);

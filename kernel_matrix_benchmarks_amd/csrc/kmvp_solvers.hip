@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(CG_BLOCKS) cg_scalars_kernel(const double* __r
       scal[2 * E + e] = rs_old > 0.0 ? v / rs_old : 0.0;
       scal[e] = v;
       const double a2 = scal[3 * E + e];
-      if (a2 > 0.0 && sqrt(v / a2) > rtol) not_met = true;
+      if (a2 > 0.0 && !(sqrt(v / a2) <= rtol)) not_met = true;  // NaN / inf: not met
     }
   }
   if (mode == 2 && threadIdx.x == 0) {
@@ -250,8 +250,10 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
 
   auto worst = [&](const std::vector<double>& r2) {
     double wv = 0.0;
-    for (int e = 0; e < E; ++e)
-      wv = std::max(wv, anorm2[e] > 0 ? std::sqrt(r2[e] / anorm2[e]) : 0.0);
+    for (int e = 0; e < E; ++e) {
+      const double v = anorm2[e] > 0 ? std::sqrt(r2[e] / anorm2[e]) : (anorm2[e] == 0 ? 0.0 : NAN);
+      if (!(v <= wv)) wv = v;  // a NaN column makes the whole verdict NaN (std::max would drop it)
+    }
     return wv;
   };
 
@@ -295,82 +297,119 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
   hipGraphExec_t gexec = nullptr;
   bool try_graph = c->comm == nullptr && getenv("KMVP_NO_GRAPH") == nullptr;
   int full_bursts = 0;
-  while (it < maxit && rel > rtol) {
-    const int burst = std::min(CG_CHECK, maxit - it);
-    if (gexec && burst == CG_CHECK) {
-      if (hipGraphLaunch(gexec, c->stream) != hipSuccess) rc = fail(c, KMVP_E_DEVICE, "hipGraphLaunch failed");
-    } else if (try_graph && full_bursts >= CG_GRAPH_AFTER && burst == CG_CHECK) {
-      // every buffer exists and every layout decision has been taken by the first burst: capture
-      if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        rc = run_burst(burst);
-        hipGraph_t graph = nullptr;
-        const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
-        if (rc == KMVP_OK && ee == hipSuccess && graph &&
-            hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
-          gexec = nullptr;
-        if (graph) (void)hipGraphDestroy(graph);
-        if (rc == KMVP_OK) {
-          if (gexec) {
-            if (hipGraphLaunch(gexec, c->stream) != hipSuccess) rc = fail(c, KMVP_E_DEVICE, "hipGraphLaunch failed");
-          } else {
-            (void)hipGetLastError();  // capture refused: nothing ran, go on launch by launch
-            try_graph = false;
-            rc = run_burst(burst);
+  double true_rel = NAN, prev_true = INFINITY;
+  // The iteration stops on the RECURRENCE residual; the verdict is on the TRUE one, a - K x, from one more
+  // product.  Where the two have drifted apart (float32 operator, ill-conditioned Gaussian matrices) the
+  // recurrence is restarted from the true residual (r = p = a - K x: "residual replacement"), at most
+  // CG_MAX_RESTARTS times and only while that still halves the true residual.
+  constexpr int CG_MAX_RESTARTS = 3;
+  for (int pass = 0;; ++pass) {
+    while (it < maxit && rel > rtol) {
+      const int burst = std::min(CG_CHECK, maxit - it);
+      if (gexec && burst == CG_CHECK) {
+        if (hipGraphLaunch(gexec, c->stream) != hipSuccess) rc = fail(c, KMVP_E_DEVICE, "hipGraphLaunch failed");
+      } else if (try_graph && full_bursts >= CG_GRAPH_AFTER && burst == CG_CHECK) {
+        // every buffer exists and every layout decision has been taken by the first burst: capture
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          rc = run_burst(burst);
+          hipGraph_t graph = nullptr;
+          const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+          if (rc == KMVP_OK && ee == hipSuccess && graph &&
+              hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
+            gexec = nullptr;
+          if (graph) (void)hipGraphDestroy(graph);
+          if (rc == KMVP_OK) {
+            if (gexec) {
+              if (hipGraphLaunch(gexec, c->stream) != hipSuccess) rc = fail(c, KMVP_E_DEVICE, "hipGraphLaunch failed");
+            } else {
+              (void)hipGetLastError();  // capture refused: nothing ran, go on launch by launch
+              try_graph = false;
+              rc = run_burst(burst);
+            }
           }
+        } else {
+          (void)hipGetLastError();
+          try_graph = false;
+          rc = run_burst(burst);
         }
       } else {
-        (void)hipGetLastError();
-        try_graph = false;
         rc = run_burst(burst);
       }
-    } else {
-      rc = run_burst(burst);
+      if (burst == CG_CHECK) ++full_bursts;
+      if (rc) {
+        c->async_product = false;
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        return rc;
+      }
+      hipError_t le = hipGetLastError();
+      if (le == hipSuccess)
+        le = hipMemcpyAsync(state.data(), scal, sizeof(double) * state.size(), hipMemcpyDeviceToHost, c->stream);
+      if (le == hipSuccess) le = hipStreamSynchronize(c->stream);
+      if (le != hipSuccess) {
+        c->async_product = false;
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        HIP_TRY(c, le);
+      }
+      for (int e = 0; e < E; ++e) rs[e] = state[e];
+      it = (int)state[(size_t)4 * E + 1];  // iterations that changed the iterate
+      rel = worst(rs);
+      if (state[(size_t)4 * E] != 0.0) break;  // the device met the tolerance inside the burst
     }
-    if (burst == CG_CHECK) ++full_bursts;
-    if (rc) {
-      c->async_product = false;
+    c->async_product = false;
+
+    // true residual ||a - K x|| / ||a|| with one more product: w.p = a (widened again) - K x
+    rc = cg_apply(c, kernel, w.x, m, E);
+    hipError_t he = hipSuccess;
+    if (!rc) he = hipMemcpyAsync(c->b_raw.p, a_host, (size_t)m * E * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream);
+    if (!rc && he == hipSuccess) {
+      if (c->dtype == KMVP_F64)
+        hipLaunchKernelGGL((cg_widen_kernel<double>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
+                           (const double*)c->b_raw.p, w.p, m * E);
+      else
+        hipLaunchKernelGGL((cg_widen_kernel<float>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
+                           (const float*)c->b_raw.p, w.p, m * E);
+      he = hipGetLastError();
+    }
+    if (!rc && he == hipSuccess) {
+      for (int e = 0; e < E; ++e) coef[e] = -1.0;
+      rc = cg_axpy(c, w.p, w.p, (const double*)c->out.p, coef, m, E, w);
+      if (!rc) rc = cg_dots(c, w.p, w.p, m, E, w, hp, rs_new);
+    }
+    if (rc || he != hipSuccess) {
       if (gexec) (void)hipGraphExecDestroy(gexec);
-      return rc;
+      if (rc) return rc;
+      HIP_TRY(c, he);
     }
-    hipError_t le = hipGetLastError();
-    if (le == hipSuccess)
-      le = hipMemcpyAsync(state.data(), scal, sizeof(double) * state.size(), hipMemcpyDeviceToHost, c->stream);
-    if (le == hipSuccess) le = hipStreamSynchronize(c->stream);
-    if (le != hipSuccess) {
-      c->async_product = false;
-      HIP_TRY(c, le);
+    true_rel = worst(rs_new);
+    const bool met = std::isfinite(true_rel) && true_rel <= rtol * 1.5;
+    if (met || !std::isfinite(true_rel) || it >= maxit || pass >= CG_MAX_RESTARTS || !(true_rel <= 0.5 * prev_true)) break;
+    // restart from the true residual: r = p = a - K x, rs_old = |r|^2, stop flag cleared (the count goes on)
+    prev_true = true_rel;
+    HIP_TRY(c, hipMemcpyAsync(w.r, w.p, vec, hipMemcpyDeviceToDevice, c->stream));
+    rs = rs_new;
+    {
+      std::vector<double> head((size_t)E);
+      for (int e = 0; e < E; ++e) head[e] = rs[e];
+      const double zero = 0.0;
+      HIP_TRY(c, hipMemcpyAsync(scal, head.data(), sizeof(double) * E, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(scal + 4 * (size_t)E, &zero, sizeof(double), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    for (int e = 0; e < E; ++e) rs[e] = state[e];
-    it = (int)state[(size_t)4 * E + 1];  // iterations that changed the iterate
-    rel = worst(rs);
-    if (state[(size_t)4 * E] != 0.0) break;  // the device met the tolerance inside the burst
+    rel = true_rel;
+    c->async_product = true;
   }
   if (gexec) (void)hipGraphExecDestroy(gexec);
-  c->async_product = false;
-
-  // true residual ||a - K x|| / ||a|| with one more product
-  if ((rc = cg_apply(c, kernel, w.x, m, E))) return rc;
-  // w.p = a (widened again) - K x
-  HIP_TRY(c, hipMemcpyAsync(c->b_raw.p, a_host, (size_t)m * E * elem_size(c->dtype), hipMemcpyHostToDevice, c->stream));
-  if (c->dtype == KMVP_F64)
-    hipLaunchKernelGGL((cg_widen_kernel<double>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
-                       (const double*)c->b_raw.p, w.p, m * E);
-  else
-    hipLaunchKernelGGL((cg_widen_kernel<float>), dim3(blocks_for(m * E)), dim3(256), 0, c->stream,
-                       (const float*)c->b_raw.p, w.p, m * E);
-  HIP_TRY(c, hipGetLastError());
-  for (int e = 0; e < E; ++e) coef[e] = -1.0;
-  if ((rc = cg_axpy(c, w.p, w.p, (const double*)c->out.p, coef, m, E, w))) return rc;
-  if ((rc = cg_dots(c, w.p, w.p, m, E, w, hp, rs_new))) return rc;
-  const double true_rel = worst(rs_new);
 
   HIP_TRY(c, hipMemcpyAsync(out_b, w.x, vec, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_signal = false;  // b_raw was used as scratch
   if (iters) *iters = it;
   if (resid) *resid = true_rel;
-  if (true_rel > rtol * 1.5 && rel > rtol) {
-    c->err = "conjugate gradients reached maxit before the requested residual";
+  // the verdict is on the TRUE residual (include/kmvp.h), with 1.5x slack for the rounding between it and the
+  // recurrence; a non-finite residual (non-finite operator or right-hand side) is never a success
+  if (!(std::isfinite(true_rel) && true_rel <= rtol * 1.5)) {
+    c->err = std::isfinite(true_rel) ? "conjugate gradients stopped before the true residual reached the requested tolerance"
+                                     : "conjugate gradients: the residual is not finite (non-finite operator or right-hand side)";
     return KMVP_E_NOT_CONVERGED;
   }
   return KMVP_OK;
@@ -498,7 +537,7 @@ __global__ void __launch_bounds__(CG_BLOCKS) minres_scalars_kernel(const double*
       T1[e] = 1.0;
       T1[E + e] = oldb > 0.0 ? -beta / oldb : 0.0;
       T1[2 * E + e] = 0.0;
-      if (S(MS_BETA1) > 0.0 && phibar / S(MS_BETA1) > rtol) not_met = true;
+      if (S(MS_BETA1) > 0.0 && !(phibar / S(MS_BETA1) <= rtol)) not_met = true;  // NaN / inf: not met
     }
   }
   if (mode == 2 && threadIdx.x == 0) {
@@ -586,8 +625,11 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
   const unsigned vb = blocks_for((int64_t)n);
   auto worst = [&]() {
     double wv = 0.0;
-    for (int e = 0; e < E; ++e)
-      if (beta1[e] > 0.0) wv = std::max(wv, state[(size_t)MS_PHIBAR * E + e] / beta1[e]);
+    for (int e = 0; e < E; ++e) {
+      if (beta1[e] == 0.0) continue;  // zero right-hand side: x = 0
+      const double v = state[(size_t)MS_PHIBAR * E + e] / beta1[e];
+      if (!(v <= wv)) wv = v;  // NaN propagates
+    }
     return wv;
   };
   auto dlin3 = [&](double* out, const double* pa, const double* pb, const double* pc, int triple) {
@@ -653,16 +695,22 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
   if ((rc = lin3(v, v, (const double*)c->out.p, nullptr))) return rc;
   if ((rc = cg_dots(c, v, v, m, E, wk, hp, dots))) return rc;
   double true_rel = 0.0;
-  for (int e = 0; e < E; ++e)
-    if (beta1[e] > 0.0) true_rel = std::max(true_rel, std::sqrt(dots[e]) / beta1[e]);
+  for (int e = 0; e < E; ++e) {
+    if (beta1[e] == 0.0) continue;
+    const double v = std::sqrt(dots[e]) / beta1[e];
+    if (!(v <= true_rel)) true_rel = v;  // NaN propagates
+  }
 
   HIP_TRY(c, hipMemcpyAsync(out_b, x, vec, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->have_signal = false;
   if (iters) *iters = it;
   if (resid) *resid = true_rel;
-  if (true_rel > rtol * 1.5 && rel > rtol) {
-    c->err = "MINRES reached maxit before the requested residual";
+  // the verdict is on the TRUE residual ||a - K x|| / ||a|| (include/kmvp.h), with 1.5x slack for the rounding
+  // between it and the recurrence the iteration stops on; a non-finite residual is never a success
+  if (!(std::isfinite(true_rel) && true_rel <= rtol * 1.5)) {
+    c->err = std::isfinite(true_rel) ? "MINRES stopped before the true residual reached the requested tolerance"
+                                     : "MINRES: the residual is not finite (non-finite operator or right-hand side)";
     return KMVP_E_NOT_CONVERGED;
   }
   return KMVP_OK;

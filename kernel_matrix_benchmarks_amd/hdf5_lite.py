@@ -5,8 +5,9 @@ the subset of the h5py API the harness uses for the reference's file formats
 (datasets.py:1-70, results.py:1-48): ``File(path, mode)``, ``f[name] = array``,
 ``f[name][:]``, ``f.attrs[key] = scalar | str | bool``, ``dict(f.attrs)``, ``close()``.
 Files written here are ordinary HDF5: float64/int64 datasets, variable-length UTF-8
-string attributes (what h5py writes for ``str``), int8 0/1 for booleans -- h5py (and so
-the reference's ``plot.py`` / ``create_website.py``) reads them back unchanged.
+string attributes (what h5py writes for ``str``), the int8 enum {FALSE = 0, TRUE = 1} h5py
+uses for booleans -- h5py (and so the reference's ``plot.py`` / ``create_website.py``) reads
+them back unchanged.  ``tests/test_file_formats.py`` checks the files with ``h5dump -H``.
 """
 import ctypes
 import ctypes.util
@@ -82,6 +83,8 @@ def _load():
         "H5Adelete": (ctypes.c_int, [hid_t, ctypes.c_char_p]),
         "H5Aexists": (ctypes.c_int, [hid_t, ctypes.c_char_p]),
         "H5Tcopy": (hid_t, [hid_t]),
+        "H5Tenum_create": (hid_t, [hid_t]),
+        "H5Tenum_insert": (ctypes.c_int, [hid_t, ctypes.c_char_p, ctypes.c_void_p]),
         "H5Tset_size": (ctypes.c_int, [hid_t, ctypes.c_size_t]),
         "H5Tset_cset": (ctypes.c_int, [hid_t, ctypes.c_int]),
         "H5Tget_class": (ctypes.c_int, [hid_t]),
@@ -141,8 +144,18 @@ class _AttrView:
                 L.H5Tclose(t)
                 return
             if isinstance(value, (bool, np.bool_)):
-                t, v = _ids["H5T_NATIVE_INT8_g"], ctypes.c_int8(int(bool(value)))
-            elif isinstance(value, (int, np.integer)):
+                # numpy.bool_ in h5py: an enum over int8 with members FALSE = 0, TRUE = 1
+                t = _check(L.H5Tenum_create(_ids["H5T_NATIVE_INT8_g"]), "H5Tenum_create")
+                for member, code in ((b"FALSE", 0), (b"TRUE", 1)):
+                    c8 = ctypes.c_int8(code)
+                    _check(L.H5Tenum_insert(t, member, ctypes.byref(c8)), "H5Tenum_insert")
+                v = ctypes.c_int8(int(bool(value)))
+                a = _check(L.H5Acreate2(fid, k, t, space, H5P_DEFAULT, H5P_DEFAULT), "H5Acreate2")
+                _check(L.H5Awrite(a, t, ctypes.byref(v)), "H5Awrite")
+                L.H5Aclose(a)
+                L.H5Tclose(t)
+                return
+            if isinstance(value, (int, np.integer)):
                 t, v = _ids["H5T_NATIVE_INT64_g"], ctypes.c_int64(int(value))
             elif isinstance(value, (float, np.floating)):
                 t, v = _ids["H5T_NATIVE_DOUBLE_g"], ctypes.c_double(float(value))

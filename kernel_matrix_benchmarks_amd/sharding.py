@@ -79,17 +79,21 @@ class Communicator:
         self.rank = int(rank)
         self.world = int(world)
         self._broadcast = broadcast_bytes
-        self._attached = set()
 
     def attach(self, ctx):
+        """Collective: every rank calls it for its context.  Whether a context already has its communicator
+        is recorded on the context object itself (``ctx.comm_world``), never by ``id(ctx)``: the runner builds
+        and frees several instances per definition and CPython hands a freed object's id to the next one, which
+        would skip the bootstrap for a fresh context and return its un-reduced partial sums as the result."""
         from kernel_matrix_benchmarks_amd import _lib
 
-        if id(ctx) in self._attached or self.world == 1:
+        if self.world == 1 or getattr(ctx, "comm_world", 0) == self.world:
             return
         uid = _lib.comm_unique_id() if self.rank == 0 else None
         uid = self._broadcast(uid)
         ctx.comm_init(uid, self.rank, self.world)
-        self._attached.add(id(ctx))
+        if getattr(ctx, "comm_world", None) != self.world:  # contexts that do not record it themselves
+            ctx.comm_world = self.world
 
 
 def torch_gloo_communicator():

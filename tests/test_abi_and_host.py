@@ -247,6 +247,63 @@ def test_pareto_front_rule():
     assert out["front"]["x"] == [4.0, 2.0, 1.0, 0.5]
 
 
+def test_pareto_front_matches_the_reference(expected):
+    """tests/golden/pareto.json: labels of "all" and "front" returned by the REFERENCE's create_pointset
+    (plotting/utils.py:15-76, run by tests/make_pareto_golden.py) on seeded point sets with ties and duplicates."""
+    import json
+
+    import make_pareto_golden
+
+    with open(os.path.join(ROOT, "tests", "golden", "pareto.json")) as f:
+        golden = json.load(f)
+    assert len(golden) == len(make_pareto_golden.CASES) * len(make_pareto_golden.AXES) == 18
+    for g in golden:
+        pts = make_pareto_golden.point_set(g["seed"], g["n"], g["ties"])
+        out = metrics.pareto_front(pts)
+        assert out["all"]["labels"] == g["all"], g["seed"]
+        assert out["front"]["labels"] == g["front"], g["seed"]
+        assert out["front"]["x"] == g["front_x"] and out["front"]["y"] == g["front_y"]
+
+
+def test_signal_and_point_shapes_are_checked_before_the_library_reads_them(monkeypatch):
+    """kmvp_set_signal copies M * E elements from the host pointer, so a signal with fewer rows than
+    the points must never reach it (the reference fails in its matmul, bruteforce.py:150)."""
+    real = _lib.Context
+
+    class Quiet:
+        comm_world = 0
+
+        def __init__(self, device=0):
+            pass
+
+        def set_option(self, key, value):
+            pass
+
+        def set_points(self, y, x, dtype, j_offset=0, M_total=None):
+            pass
+
+    monkeypatch.setattr(_lib, "Context", Quiet)
+    y = np.random.RandomState(0).rand(50, 3)
+    p = mi355x.MI355XProduct(kernel="gaussian", dimension=3)
+    p.prepare_data(source_points=y, target_points=y, same_points=True)
+    with pytest.raises(ValueError):
+        p.prepare_query(source_signal=np.ones((49, 1)))
+    with pytest.raises(ValueError):
+        p.prepare_query(source_signal=np.ones((51, 2)))
+    s = mi355x.MI355XSolver(kernel="gaussian", dimension=3)
+    s.prepare_data(source_points=y)
+    with pytest.raises(ValueError):
+        s.prepare_query(target_signal=np.ones((49, 1)))
+    # the typed wrapper checks too (callers of the C ABI through _lib.Context)
+    c = real.__new__(real)  # no GPU: the object is never bound to a kmvp_ctx, the checks come first
+    c._ctx = None
+    c.M, c.N, c.D = 50, 50, 3
+    with pytest.raises(ValueError):
+        real.set_signal(c, np.ones((49, 1), dtype=np.float32))
+    with pytest.raises(ValueError):
+        real.cg_solve(c, "gaussian", np.ones((49, 1)), 1e-6, 10)
+
+
 class OracleBackedProduct(base.BaseProduct):
     """TEST-ONLY plugin (lives in tests/): lets the runner protocol be exercised on a
     machine without a GPU.  Not part of the product."""
@@ -315,3 +372,36 @@ def test_runner_protocol_and_result_files(tmp_path):
         f.close()
     pts, front = metrics.summarize_results(name, root=str(tmp_path / "results"))
     assert len(pts) == 2 and len(front["front"]["labels"]) >= 1
+
+
+def test_config1_plumbing_at_1e4_on_cpu(tmp_path):
+    """BASELINE config 1 (Gaussian, uniform-3D, N = M = 1e4, E = 1, float64, CPU plumbing): the dataset recipe ->
+    registry -> runner protocol -> result file chain at the config's own size, with the oracle-backed TEST plugin
+    standing where the GPU plugin stands (no GPU here).  The truth comes from the C oracle, the run from the numpy
+    oracle: two restatements of bruteforce.py:25-58,130-153 that must agree to rounding at 1e8 pairs."""
+    import c_oracle
+
+    n = 10000
+    name = f"product-cube-D3-E1-M{n}-N{n}-gaussian"
+    y, b = datasets.cube_points(n, 3)  # seed 10003 (datasets.py:258)
+    yo, bo = kmvp_oracle.uniform_cube(n, 3)
+    assert np.array_equal(y, yo) and np.array_equal(b, bo)
+    truth = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=np.arange(n))
+    data_root = str(tmp_path / "data")
+    datasets.write_dataset(filename=datasets.dataset_path(name, data_root), task="product", kernel="gaussian",
+                           source_points=y, source_signal=b, target_signal=truth)
+    yaml_file = tmp_path / "algos.yaml"
+    yaml_file.write_text(
+        "oracle-backed:\n  hardware: CPU\n  product: true\n  docker-tag: none\n"
+        "  module: test_abi_and_host\n  constructor: OracleBackedProduct\n  run-groups:\n    g:\n"
+        "      datasets: ['*-gaussian']\n      args: [{precision: float64}]\n")
+    out = runner.run_dataset(name, hardware="CPU", runs=1, definition_file=str(yaml_file), data_root=data_root,
+                             results_root=str(tmp_path / "results"), verbose=False)
+    (fn, attrs, result), = out
+    assert result.shape == (n, 1) and attrs["run_count"] == 1 and attrs["dataset"] == name
+    f = storage.open_file(fn, "r")
+    try:
+        err = metrics.result_errors(np.asarray(f["error"][:]))
+    finally:
+        f.close()
+    assert err["max"] / np.max(np.abs(truth)) < 1e-12, err
