@@ -607,6 +607,7 @@ def test_source_shard_with_global_offset_matches_oracle():
         for lo, hi in ((0, 130), (130, 257)):
             ctx = _lib.Context(0)
             try:
+                ctx.set_option("partial_shard", 1)  # this shard's partial sums, on purpose: added up below
                 ctx.set_points(np.ascontiguousarray(y[lo:hi]), x, _lib.KMVP_F64, j_offset=lo, M_total=257)
                 ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
                 ctx.run(kernel, False)
@@ -756,6 +757,7 @@ def test_inverse_distance_1e6_row_subset_with_sharded_offsets():
         ctx = _lib.Context(0)
         try:
             ctx.set_option("same_points_global", 1)  # what the plugin sets for sharded same_points
+            ctx.set_option("partial_shard", 1)
             ctx.set_points(np.ascontiguousarray(y[lo:hi], dtype=np.float32), y.astype(np.float32),
                            _lib.KMVP_F32, j_offset=lo, M_total=n)
             ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
@@ -767,6 +769,249 @@ def test_inverse_distance_1e6_row_subset_with_sharded_offsets():
     assert np.isfinite(total).all()  # the diagonal was zeroed by GLOBAL index in both shards
     want = c_oracle.product(kernel="inverse-distance", source_points=y, source_signal=b, rows=rows)
     assert np.max(np.abs(total[rows] - want)) / np.max(np.abs(want)) <= 2 * TOL32
+
+
+# ---- every BASELINE config at ITS OWN size ------------------------------------------
+
+def test_config1_gaussian_1e4_float64_all_rows():
+    """C1 (Gaussian, uniform-3D, N = M = 1e4, E = 1, float64): every row against the numpy oracle
+    (bruteforce.py:25-58,130-153 restated), and the float32 run inside the north-star tolerance."""
+    n = 10_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)  # seed 10003
+    want = kmvp_oracle.product(kernel="gaussian", source_points=y, source_signal=b)
+    got, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, np.float64)
+    assert got.shape == (n, 1) and rel_err(got, want) <= TOL64, rel_err(got, want)
+    got32, _ = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32")
+    assert rel_err(got32, want) <= TOL32, rel_err(got32, want)
+
+
+def test_config2_cell_kernel_on_all_rows_against_the_float64_difference_form():
+    """C2 at full size, ALL 1e6 rows: the cell form (exp() range-reduced by grid cells, remainder polynomial on
+    the matrix cores -- an approximating kernel) against the float64 difference form lowd_kernel<double>
+    (golden-pinned to 1e-11 and, here, to the C oracle on 256 rows) on the same points, with the float32
+    difference form beside it.  A mis-tiled boundary cell or a dropped tile shows up here; a 0.1 % row sample,
+    or the linearity / symmetry checks, would let it through."""
+    n = 1_000_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    truth_algo = MI355XProduct(kernel="gaussian", dimension=3, precision=np.float64, fast_sqdists=False)
+    try:
+        truth_algo.prepare_data(source_points=y, target_points=y, same_points=True)
+        truth_algo.prepare_query(source_signal=b)
+        truth_algo.query()
+        assert truth_algo.device_kernel == "lowd_kernel"
+        truth = truth_algo.get_result()
+    finally:
+        truth_algo.done()
+    rows = np.random.RandomState(0).choice(n, size=256, replace=False)
+    want = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=rows)
+    assert np.max(np.abs(truth[rows] - want)) / np.max(np.abs(want)) <= TOL64
+    algo = MI355XProduct(kernel="gaussian", dimension=3, precision="float32")
+    try:
+        algo.prepare_data(source_points=y, target_points=y, same_points=True)
+        algo.fit()
+        algo.prepare_query(source_signal=b)
+        algo.query()
+        assert algo.device_kernel == "cell_kernel"  # what auto picks at the headline shape
+        cells = algo.get_result()
+        algo.set_query_arguments(fast_sqdists=0)
+        algo.query()
+        assert algo.device_kernel == "lowd_kernel"
+        diff = algo.get_result()
+    finally:
+        algo.done()
+    scale = np.max(np.abs(truth))
+    e_cell = np.max(np.abs(cells - truth)) / scale
+    e_diff = np.max(np.abs(diff - truth)) / scale
+    print(f"config 2, all 1e6 rows vs float64: cell form {e_cell:.2e}, float32 difference form {e_diff:.2e}")
+    assert e_cell <= 1e-6, e_cell   # measured 4-6e-7: every row, not a sample
+    assert e_diff <= TOL32, e_diff
+
+
+def test_cell_kernel_worst_case_placement_in_opposite_cell_corners():
+    """The remainder polynomial of the cell form is truncated (exp(t) ~ 1 + t + t^2/2, |t| = |2 d.e| <= 0.016):
+    its error is largest for a target in one corner of its cell and a source in the far corner of a cell
+    diagonal to it (d and e parallel, both at the full half-diagonal).  This cloud is built to be exactly that:
+    every point sits within 2 % of a cell side of a corner of its cell, half of the cells' points in the
+    (-,-,-) corner and half in the (+,+,+) corner, 65 536 points, so every target sees its worst-placed sources
+    at EVERY distance.  Checked against the float64 oracle on all rows; the difference form on the same data
+    is the yardstick."""
+    rs = np.random.RandomState(77)
+    g = 8                       # 8 x 8 x 8 cells over [0, 0.8]^3: side 0.1 <= sqrt(0.032 / 3) = 0.1033
+    n_cell = 128                # 65 536 points >= 32768, four full tiles per cell
+    cells = np.stack(np.meshgrid(np.arange(g), np.arange(g), np.arange(g), indexing="ij"), axis=-1).reshape(-1, 3)
+    h = 0.1
+    pts = []
+    for c in cells:
+        lo_corner = c * h + rs.rand(n_cell // 2, 3) * 0.02 * h
+        hi_corner = (c + 1) * h - rs.rand(n_cell // 2, 3) * 0.02 * h
+        pts.append(lo_corner)
+        pts.append(hi_corner)
+    y = np.concatenate(pts)
+    # pin the bounding box to [0, 0.8]^3 so that the library's box-fitted grid IS this grid
+    y[0] = 0.0
+    y[-1] = g * h
+    y = y[rs.permutation(len(y))]
+    n = len(y)
+    assert n >= 32768
+    b = np.abs(rs.randn(n, 1)) + 0.5  # one sign: truncation errors (all of one sign for parallel d, e) cannot cancel
+    want = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=np.arange(n))  # float64, all rows
+    got, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32", fast_sqdists="cells")
+    assert extra["device_kernel"] == "cell_kernel"
+    ref, extra0 = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32", fast_sqdists=False)
+    assert extra0["device_kernel"] == "lowd_kernel"
+    e_cell, e_diff = rel_err(got, want), rel_err(ref, want)
+    assert e_cell <= TOL32, (e_cell, e_diff)
+    # the design bound (kmvp_cell.hpp): <= 6.8e-7 truncation + ~5e-7 of bf16 rounding for the worst placed pair
+    assert e_cell <= 1.5e-6, (e_cell, e_diff)
+    # whatever the plugin picks by itself on this cloud stays inside the tolerance as well
+    auto, extra_auto = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32")
+    assert rel_err(auto, want) <= TOL32, extra_auto
+    print(f"worst-case placement: cell form {e_cell:.2e}, difference form {e_diff:.2e}, auto = {extra_auto['device_kernel']}")
+
+
+def test_config4_inverse_distance_one_of_eight_shards_at_full_size():
+    """C4 (inverse-distance, uniform-3D, N = M = 1e7, E = 1, float32, sources sharded over 8 GPUs): what ONE of
+    the 8 ranks computes -- all 1e7 targets x its 1.25e6 sources, with the zero rule of bruteforce.py:8-15 on
+    the GLOBAL flat index (j_offset / M_total) -- at the config's own size.  All rows finite (the diagonal
+    falls inside rank 3's slice and must be zeroed there); 512 rows against the C oracle's shard sums."""
+    n = 10_000_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)  # seed 10000003
+    rank, world = 3, 8
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    y32 = y.astype(np.float32)
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_option("same_points_global", 1)  # what the plugin sets for sharded same_points
+        ctx.set_option("partial_shard", 1)       # one rank's partial sums, on purpose (no communicator here)
+        ctx.set_points(np.ascontiguousarray(y32[lo:hi]), y32, _lib.KMVP_F32, j_offset=lo, M_total=n)
+        ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
+        ctx.run("inverse-distance", False)
+        kname, ms, dev_gb = ctx.last_kernel_name, ctx.last_kernel_ms, ctx.device_bytes / 1e9
+        part = ctx.get_result(n, 1)
+    finally:
+        ctx.close()
+    assert kname == "cfast_kernel", kname
+    assert np.isfinite(part).all()
+    rows = np.concatenate([np.random.RandomState(4).choice(n, size=448, replace=False),
+                           np.arange(lo, lo + 32), np.arange(hi - 32, hi)])  # incl. rows whose zero column is in the slice
+    want, _ = c_oracle.product(kernel="inverse-distance", source_points=y[lo:hi], target_points=y, source_signal=b[lo:hi],
+                               rows=rows, j_offset=lo, M_total=n, raw_sums=True)
+    err = np.max(np.abs(part[rows] - want)) / np.max(np.abs(want))
+    assert err <= 2 * TOL32, err
+    print(f"config 4 shard: {kname} {ms:.1f} ms, {n * (hi - lo) / ms / 1e9:.2f}e12 pairs/s, {dev_gb:.2f} GB, rel err {err:.2e}")
+
+
+def test_config5_gaussian_cg_solver_at_1e5_float64():
+    """C5 exactly (Gaussian solver K b = a, N = M = 1e5, D = 3, float64, CG with the HIP matvec as operator,
+    residual < 1e-6): uniform_cube(100000, 3) (seed 100003), a := K b from the float64 product,
+    MI355XSolver(rtol=1e-6).  Judged on the residual (the reference's lstsq, bruteforce.py:193-207,
+    cannot run at 80 GB): the solver's own true residual, and the oracle's on 256 rows."""
+    n = 100_000
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    prod = MI355XProduct(kernel="gaussian", dimension=3, precision=np.float64)
+    try:
+        prod.prepare_data(source_points=y, target_points=y, same_points=True)
+        prod.fit()
+        prod.prepare_query(source_signal=b)
+        prod.query()
+        a = prod.get_result()
+        assert prod.device_kernel == "cell64_kernel"
+    finally:
+        prod.done()
+    rows = np.random.RandomState(3).choice(n, size=256, replace=False)
+    a_rows = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=rows)
+    assert np.max(np.abs(a[rows] - a_rows)) / np.max(np.abs(a_rows)) <= TOL64
+    algo = MI355XSolver(kernel="gaussian", dimension=3, precision=np.float64, rtol=1e-6, maxit=2000)
+    try:
+        algo.prepare_data(source_points=y)
+        algo.fit()
+        algo.prepare_query(target_signal=a)
+        algo.query()
+        sol = algo.get_result()
+        info = algo.get_additional()
+    finally:
+        algo.done()
+    assert info["cg_converged"], info
+    assert info["device_kernel"] == "cell64_kernel", info
+    assert info["cg_relative_residual"] <= 1.5e-6, info  # the TRUE residual (kmvp.h), 1.5x slack over the recurrence's
+    assert sol.shape == (n, 1) and np.isfinite(sol).all()
+    Kb = c_oracle.product(kernel="gaussian", source_points=y, source_signal=sol, rows=rows)
+    res_rows = np.linalg.norm(Kb - a[rows]) / np.linalg.norm(a[rows])
+    assert res_rows <= 1e-5, (res_rows, info)
+    print(f"config 5: {info['cg_iterations']} iterations, residual {info['cg_relative_residual']:.2e}, rows {res_rows:.2e}")
+
+
+def test_solver_verdict_is_the_true_residual_and_never_nan():
+    """KMVP_OK only for a finite TRUE residual <= 1.5 rtol.  A NaN right-hand side, or an operator
+    with inf entries (inverse-distance with a duplicated point under MINRES), is not a success."""
+    n = 600
+    y, _ = kmvp_oracle.uniform_cube(n, 3)
+    a = np.random.RandomState(1).randn(n, 1)
+    bad = a.copy()
+    bad[17, 0] = np.nan
+    for kernel in ("gaussian", "inverse-distance"):
+        ctx = _lib.Context(0)
+        try:
+            ctx.set_points(y, None, _lib.KMVP_F64)
+            sol, iters, resid, ok = ctx.cg_solve(kernel, bad, 1e-8, 200)
+        finally:
+            ctx.close()
+        assert not ok and not np.isfinite(resid), (kernel, iters, resid, ok)
+    dup = y.copy()
+    dup[5] = dup[400]  # coincident off-diagonal points: 1/sqrt(0) = inf in the matrix (bruteforce.py:8-15)
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_points(dup, None, _lib.KMVP_F64)
+        sol, iters, resid, ok = ctx.cg_solve("inverse-distance", a, 1e-8, 200)
+    finally:
+        ctx.close()
+    assert not ok, (iters, resid)
+    # a float32 operator on an ill-conditioned Gaussian system: whatever is returned as converged has a TRUE
+    # residual within 1.5 rtol (checked against the float64 oracle, not against the solver's own number)
+    n2 = 3000
+    y2, b2 = kmvp_oracle.uniform_cube(n2, 3)
+    a2 = kmvp_oracle.product(kernel="gaussian", source_points=y2, source_signal=b2)
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_points(y2.astype(np.float32), None, _lib.KMVP_F32)
+        sol, iters, resid, ok = ctx.cg_solve("gaussian", a2.astype(np.float32), 1e-4, 3000)
+    finally:
+        ctx.close()
+    true = kmvp_oracle.relative_residual(kernel="gaussian", source_points=y2, solution=sol, target_signal=a2)
+    assert ok == (resid <= 1.5e-4)
+    if ok:
+        assert true <= 3e-4, (true, resid)  # float32 operator vs float64 oracle: a factor of 2 between the two views
+
+
+def test_runner_drives_the_headline_dataset_under_its_reference_name(tmp_path):
+    """the large synthetic config registered under the reference's naming pattern
+    (algos.yaml:38) and driven through the runner: product-cube-D3-E1-M1000000-N1000000-gaussian.
+    The truth is the float64 HIP product (datasets.ground_truth), itself pinned at 1e6 by the oracle rows here."""
+    from kernel_matrix_benchmarks_amd import datasets, metrics, runner
+
+    name = "product-cube-D3-E1-M1000000-N1000000-gaussian"
+    stored = runner.run_dataset(name, hardware="GPU", runs=2, data_root=str(tmp_path / "data"),
+                                results_root=str(tmp_path / "results"), verbose=False)
+    by_name = {attrs["name"]: (attrs, result) for _, attrs, result in stored}
+    assert sorted(by_name) == ["MI355XProduct(float32)", "MI355XProduct(float64)"]
+    f, D = datasets.get_dataset(name, root=str(tmp_path / "data"))
+    try:
+        y = np.asarray(f["source_points"][:])
+        b = np.asarray(f["source_signal"][:])
+        truth = np.asarray(f["target_signal"][:])
+        assert bool(f.attrs["same_points"]) and f.attrs["kernel"] == "gaussian"
+    finally:
+        f.close()
+    yo, bo = kmvp_oracle.uniform_cube(1_000_000, 3)
+    assert np.array_equal(y, yo) and np.array_equal(b, bo)
+    rows = np.random.RandomState(5).choice(1_000_000, size=256, replace=False)
+    want = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=rows)
+    assert np.max(np.abs(truth[rows] - want)) / np.max(np.abs(want)) <= TOL64
+    a32, r32 = by_name["MI355XProduct(float32)"]
+    a64, r64 = by_name["MI355XProduct(float64)"]
+    assert a32["device_kernel"] == "cell_kernel" and a64["device_kernel"] == "cell64_kernel"
+    assert metrics.relative_max_error(r32, truth) <= TOL32 and metrics.relative_max_error(r64, truth) <= TOL64
+    assert a32["query_time"] < 0.2 and a32["build_time"] < 0.2 and a32["run_count"] == 2
 
 
 # ---- solver

@@ -12,6 +12,7 @@ order = sharding.spatial_order(y)
 lo, hi = sharding.shard_range(n, 0, 8)
 ys, bs = y[order][lo:hi], b[order][lo:hi]
 ctx = _lib.Context(0)
+ctx.set_option("partial_shard", 1)  # a shard without a communicator, on purpose
 ctx.set_points(np.ascontiguousarray(ys), y, _lib.KMVP_F32, j_offset=lo, M_total=n)
 ctx.set_signal(np.ascontiguousarray(bs))
 for _ in range(3):

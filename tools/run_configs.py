@@ -41,6 +41,7 @@ if "4" in which:
         ctx = _lib.Context(0)
         ctx.set_option("fast_sqdists", opt)
         ctx.set_option("same_points_global", 1)  # the targets ARE the full source set (what the sharded plugin sets)
+ctx.set_option("partial_shard", 1)  # a shard without a communicator, on purpose
         ctx.set_points(np.ascontiguousarray(y[lo:hi], dtype=np.float32), y.astype(np.float32), _lib.KMVP_F32, j_offset=lo, M_total=n)
         ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
         ctx.run("inverse-distance", False)
