@@ -54,10 +54,11 @@ class MI355XProduct(BaseProduct):
         # |x|^2+|y|^2-2x.y form around one centre (matrix cores), False = difference form,
         # "centred" = expanded around per-group centres with exact recomputation of the closest
         # pairs; "cells" = the Gaussian's exp() range-reduced by grid cells, polynomial remainder
-        # on the matrix cores (D <= 3); None lets the library pick the cheapest form that is as
-        # accurate as the difference form.
-        if fast_sqdists not in (None, False, True, "centred", "cells"):
-            raise ValueError("fast_sqdists must be None, False, True, 'centred' or 'cells'")
+        # on the matrix cores (D <= 3: cellmm_kernel, which also sums over the sources in the MFMA
+        # accumulator, where it applies; "cells-valu" = always cell_kernel, which sums on the VALU);
+        # None lets the library pick the cheapest form that is as accurate as the difference form.
+        if fast_sqdists not in (None, False, True, "centred", "cells", "cells-valu"):
+            raise ValueError("fast_sqdists must be None, False, True, 'centred', 'cells' or 'cells-valu'")
         self.fast_sqdists = fast_sqdists
         self._options = dict(targets_per_lane=targets_per_lane, feed=feed, segments=segments,
                              chunk=chunk, fast_tiles=fast_tiles)
@@ -86,7 +87,7 @@ class MI355XProduct(BaseProduct):
                 if value:
                     self._ctx.set_option(key, value)
             if self.fast_sqdists is not None:
-                code = {"centred": 2, "cells": 3}.get(self.fast_sqdists, int(bool(self.fast_sqdists)))
+                code = {"centred": 2, "cells": 3, "cells-valu": 4}.get(self.fast_sqdists, int(bool(self.fast_sqdists)))
                 self._ctx.set_option("fast_sqdists", code)
         world = 1 if self.comm is None else self.comm.world
         if world > 1:

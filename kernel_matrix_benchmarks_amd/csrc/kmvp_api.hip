@@ -90,7 +90,7 @@ void kmvp_destroy(kmvp_ctx* c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled, &c->y_scaled,
                     &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg,
-                    &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre})
+                    &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre, &c->cell_scale})
     release(*b);
   for (int i = 0; i < 5; ++i)
     if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -262,7 +262,7 @@ int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
     if (value < 0 || value > 65535) return fail(c, KMVP_E_INVALID, "segments out of range");
     c->opt_segments = (int)value;
   } else if (k == "fast_sqdists") {
-    if (value < -1 || value > 3) return fail(c, KMVP_E_INVALID, "fast_sqdists must be -1 (auto), 0, 1, 2 or 3");
+    if (value < -1 || value > 4) return fail(c, KMVP_E_INVALID, "fast_sqdists must be -1 (auto), 0, 1, 2, 3 or 4");
     c->opt_fast = (int)value;
   } else if (k == "same_points_global") {
     c->opt_same_global = value != 0;
@@ -286,7 +286,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
   size_t t = 0;
   for (const DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled,
                           &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg,
-                          &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre})
+                          &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre, &c->cell_scale})
     t += b->cap;
   return (int64_t)t;
 }

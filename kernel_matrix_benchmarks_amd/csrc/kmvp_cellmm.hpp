@@ -1,0 +1,309 @@
+// Gaussian pair loop with the kernel value AND the sum over the sources on the matrix cores.
+//
+// cell_kernel (kmvp_cell.hpp) takes the remainder polynomial of the range-reduced exponential from one
+// bf16 MFMA per 32 x 32 pairs and still spends ONE VALU FMA PER PAIR on weighting it with W_j b_j and
+// summing over the sources: 22.5 VALU instructions per 32 x 32 tile pair, VALU issue saturated, the matrix
+// pipe 37 % busy (profiles/r01_gaussian_1e6_f32_cell_kernel_sq_counters.txt).  Here the weight moves INTO
+// the source operand and the sum INTO the MFMA's accumulator:
+//
+//     exp(-|x_i - y_j|^2) b_j = U_i(S) * [ W_j(T) b_j * exp(t_ij) ] ,  t_ij = 2 d_i.e_j ,  |t| <= 0.016
+//         (x_i = c_T + d_i, y_j = c_S + e_j, D = c_T - c_S, U_i(S) = exp(-|x_i - c_S|^2),
+//          W_j(T) = exp(e_j.(2 D - e_j)); see kmvp_cell.hpp)
+//     W_j b_j exp(t_ij) = W_j b_j  +  sum_k A_jk(T) B_ki ,   A_jk = psi_k(e_j) * W_j(T) b_j ,  B_ki = phi_k(d_i)
+//
+// with the fifteen monomial pairs of t + t^2/2 as the K = 16 contraction index of ONE
+// v_mfma_f32_32x32x16_f16 per 32 sources x 32 targets, whose fp32 accumulator (row = source, column =
+// target) is carried from source tile to source tile of a source cell:  acc += A_tile(T) x B.  The VALU
+// touches a pair of tiles only to rebuild A for the wave's target cell -- ~32 instructions per source tile,
+// shared by the TT = 8 target tiles of the wave, i.e. 4 per tile pair instead of 22.5 -- and, once per
+// (target tile, source CELL), to fold the accumulator: 15 adds over its 16 rows, one cross-half add,
+// times U_i(S), into an fp64 sum.  The constant term W_j b_j of the bracket does not depend on the target
+// inside a cell: it is summed per lane in fp32 as the rows of A are built and joins the accumulator's row
+// sum at the fold (exact in fp32, where an f16 operand would have needed three more slots).  Every pair is
+// still evaluated -- sixteen multiply-adds per pair on the matrix pipe -- and nothing is truncated in
+// space.
+//
+// Precision.  f16 operands (11 significant bits), fp32 products and accumulation.  Slots (k = 8 h + j for
+// lane half h, register pair j/2):
+//     h = 0:  d_xh e'_xh, d_yh e'_yh, d_xh e'_xm, d_yh e'_ym, d_xm e'_xh, d_ym e'_yh, (d_x^2/2)(e'_x f_x), (d_y^2/2)(e'_y f_y)
+//     h = 1:  d_zh e'_zh, d_xd_z(e'_x f_z), d_zh e'_zm, d_xd_z(rest), d_zm e'_zh, d_yd_z(e'_y f_z), (d_z^2/2)(e'_z f_z), d_xd_y(e'_x f_y)
+// with f = 2 e, e' = f W b and v = v_h + v_m the two-way f16 split (22 bits).  Linear terms: dropped
+// d_m e'_m <= 2^-22 |t| = 4e-9; quadratic terms (<= 1.3e-4) in one f16 product each: <= 1.3e-7 in the worst
+// corner, ~1e-8 typically; truncation t^3/6 as in cell_kernel (<= 6.8e-7 corner to corner, ~1e-8 typical).
+// Operands are scaled by powers of two into the normal range of f16 (targets x 2^6; the signal by
+// sigma_b = 2^(15 - ceil(log2(0.104 Wmax max|b|))), kmvp_cellmm_pack.hpp), undone exactly at the store.
+//
+// Mapping: a wave owns TT target tiles of ONE cell (cells are padded to multiples of TT tiles); a workgroup
+// of 4 waves shares LDS stages of 12 source tiles (32 x (f_x, f_y, f_z, -|e|^2 log2 e), 32 x b, cell
+// header) prefetched through registers, double buffered, one barrier per stage.  TT = 8: 128 accumulator registers
+// per lane, two waves per SIMD -- while one wave's eight MFMAs (256 matrix-pipe cycles) run, the other
+// builds its next A.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmvp_cell.hpp"  // CellGrid, CELL_TILE, CELL_T_MAX, f32x4, f32x16, kexp2, block_to_work
+
+namespace kmvp {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CMM_STAGE_TILES = 12;
+constexpr int CMM_STAGE_BYTES = 8192;
+constexpr int CMM_E_OFF = 0;                                          // [tile][32][f_x, f_y, f_z, g]
+constexpr int CMM_B_OFF = CMM_STAGE_TILES * CELL_TILE * 16;           // [tile][32] b sigma_b
+constexpr int CMM_HDR_OFF = CMM_B_OFF + CMM_STAGE_TILES * CELL_TILE * 4;  // [tile] c_x, c_y, c_z, key
+static_assert(CMM_HDR_OFF + CMM_STAGE_TILES * 16 <= CMM_STAGE_BYTES, "stage image too small");
+constexpr float CMM_TARGET_SCALE = 64.f;   // targets' offsets x 2^6: their f16 mid parts stay normal numbers
+constexpr int CMM_MAX_WLOG2 = 8;           // W_j <= 2^8 or the path is not taken (kmvp_product.hip)
+
+struct CellmmArgs {
+  const float* xd;           // targets [n_slots][4]: d_x, d_y, d_z, 0 (cell-sorted, tiles padded)  -- as cell_kernel
+  const float* tmeta;        // target tiles [n_slots / 32][4]: c_x, c_y, c_z, cell key (bit 30: empty tile)
+  const unsigned char* img;  // source stages [m_stages][CMM_STAGE_BYTES]
+  const float* scale;        // [0] sigma_b, [1] 1 / (sigma_b * 2^6)
+  double* part;              // partial sums [segments][1][n_slots]
+  int64_t n_slots;
+  int64_t m_stages;
+  int64_t seg_stages;
+  int segments;
+  int tile_blocks;
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// two floats -> packed f16 pair in ONE instruction (v_cvt_pkrtz_f16_f32, round toward zero: the high parts'
+// remainders are formed exactly afterwards; mid parts and quadratic terms lose at most 2^-10 of themselves)
+__device__ __forceinline__ f16x2 cellmm_pk(float a, float b) {
+  return __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+// B operand of one target (column) for lane half h: see the slot table in the header comment
+__device__ __forceinline__ f16x8 cellmm_target_operand(const f32x4 d, int h) {
+  float s[3], sh[3], sm[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    s[c] = d[c] * CMM_TARGET_SCALE;
+    sh[c] = (float)(_Float16)s[c];
+    sm[c] = s[c] - sh[c];
+  }
+  const float q = CMM_TARGET_SCALE;  // quadratic monomials carry 2^6 as well: A's e' f carries sigma_b only
+  float lo[8], hi[8];
+  lo[0] = sh[0]; lo[1] = sh[1]; lo[2] = sh[0]; lo[3] = sh[1]; lo[4] = sm[0]; lo[5] = sm[1];
+  lo[6] = d[0] * d[0] * (0.5f * q);
+  lo[7] = d[1] * d[1] * (0.5f * q);
+  hi[0] = sh[2]; hi[1] = d[0] * d[2] * q; hi[2] = sh[2]; hi[3] = d[0] * d[2] * q; hi[4] = sm[2];
+  hi[5] = d[1] * d[2] * q;
+  hi[6] = d[2] * d[2] * (0.5f * q);
+  hi[7] = d[0] * d[1] * q;
+  f16x8 out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = (_Float16)(h ? hi[j] : lo[j]);
+  return out;
+}
+
+template <int TT>
+__global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(TT >= 8 ? 2 : 1))) cellmm_kernel(const CellmmArgs a) {
+  constexpr int SB = CMM_STAGE_BYTES;
+  constexpr int PIECES = SB / (16 * BLOCK_THREADS);
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][SB];
+
+  int tb, seg;
+  block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
+
+  // TT = 8 keeps the targets' offsets in LDS (needed again only when U is recomputed, once per source cell)
+  constexpr bool HOLD_D = TT < 8;
+  __shared__ __attribute__((aligned(16))) float dsh[HOLD_D ? 1 : WAVES_PER_BLOCK][HOLD_D ? 1 : TT][CELL_TILE][4];
+  float dl[HOLD_D ? TT : 1][3], cT[3], U[TT];
+  f16x8 xb[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.xd + ((tile0 + tt) * CELL_TILE + r) * 4);
+    const f32x4 m = *reinterpret_cast<const f32x4*>(a.tmeta + (tile0 + tt) * 4);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if constexpr (HOLD_D) dl[tt][c] = v[c];
+      else if (h == 0) dsh[wave][tt][r][c] = v[c];
+      if (tt == 0) cT[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[c])));  // one cell per wave
+    }
+    xb[tt] = cellmm_target_operand(v, h);
+    U[tt] = 0.f;
+  }
+
+  f32x16 acc[TT];
+  double outd[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    outd[tt] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[tt][k] = 0.f;
+  }
+
+  const int64_t s_begin = (int64_t)seg * a.seg_stages;
+  int64_t s_end = s_begin + a.seg_stages;
+  if (s_end > a.m_stages) s_end = a.m_stages;
+
+  // Stage s + 1 travels through registers: requested when stage s starts, written to LDS when stage s is done.
+  // (LDS-DMA would save the registers, but the compiler then waits for the copy -- vmcnt(0) -- in front of the
+  // first LDS read after its issue, i.e. at the START of the stage it was supposed to hide behind.)
+  f32x4 pre[PIECES];
+  auto fetch = [&](int64_t s) {
+    const unsigned char* src = a.img + s * SB;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      pre[p] = *reinterpret_cast<const f32x4*>(src + (p * BLOCK_THREADS + (int)threadIdx.x) * 16);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      *reinterpret_cast<f32x4*>(&lds[buf][(p * BLOCK_THREADS + (int)threadIdx.x) * 16]) = pre[p];
+  };
+  if (s_begin < s_end) {
+    fetch(s_begin);
+    commit(0);
+  }
+  __syncthreads();
+
+  int key_s = -2;     // cell of the source tiles the accumulators hold (-2: nothing yet)
+  float S0 = 0.f;     // sum of W_j b_j over this lane's source row, tiles of the current cell
+  float D1[3] = {0.f, 0.f, 0.f};  // log2 e (c_T - c_S)
+
+  // fold of the accumulators of the finished source cell into the fp64 sums
+  auto fold = [&]() {
+    float s0 = S0;
+    s0 += __shfl_xor(s0, 16);
+    s0 += __shfl_xor(s0, 8);
+    s0 += __shfl_xor(s0, 4);
+    s0 += __shfl_xor(s0, 2);
+    s0 += __shfl_xor(s0, 1);
+    s0 *= CMM_TARGET_SCALE;  // the accumulators carry the targets' 2^6
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const f32x16 d = acc[tt];
+      float v0 = (d[0] + d[1]) + (d[2] + d[3]);
+      float v1 = (d[4] + d[5]) + (d[6] + d[7]);
+      float v2 = (d[8] + d[9]) + (d[10] + d[11]);
+      float v3 = (d[12] + d[13]) + (d[14] + d[15]);
+      float v = (v0 + v1) + (v2 + v3);
+      v += __shfl_xor(v, 32);
+      outd[tt] += (double)(U[tt] * (v + s0));
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[tt][k] = 0.f;  // the next source cell starts from zero
+    }
+    S0 = 0.f;
+  };
+
+  // A = psi_k(e_j) W_j(T) b_j of source tile q for source row r, k-half h (~30 VALU instructions); wb = W_j b_j
+  auto build = [&](int buf, int q, float& wb) -> f16x8 {
+    const f32x4 ef = *reinterpret_cast<const f32x4*>(&lds[buf][CMM_E_OFF + (q * CELL_TILE + r) * 16]);
+    const float bq = *reinterpret_cast<const float*>(&lds[buf][CMM_B_OFF + (q * CELL_TILE + r) * 4]);
+    const float arg = fmaf(ef[0], D1[0], fmaf(ef[1], D1[1], fmaf(ef[2], D1[2], ef[3])));
+    wb = kexp2(arg) * bq;
+    const float px = ef[0] * wb, py = ef[1] * wb, pz = ef[2] * wb;  // e' = f W b (x sigma_b)
+    const float u1 = h ? pz : px;                  // split: x | z
+    const float u2 = h ? px * ef[2] : py;          // split: y | the x z monomial
+    const f16x2 R0 = cellmm_pk(u1, u2);
+    const float c1 = (float)R0[0], c2 = (float)R0[1];
+    const f16x2 R1 = cellmm_pk(u1 - c1, u2 - c2);
+    const float q1 = u1 * (h ? ef[2] : ef[0]);     // x x | z z
+    const float v2 = (h ? px : py) * ef[1];        // y y | x y
+    const f16x2 R3 = cellmm_pk(q1, v2);
+    const f16x2 R2 = cellmm_pk(c1, h ? py * ef[2] : c2);  // (x_h, y_h) | (z_h, y z)
+    i32x4 yw;
+    yw[0] = __builtin_bit_cast(int, R0);
+    yw[1] = __builtin_bit_cast(int, R1);
+    yw[2] = __builtin_bit_cast(int, R2);
+    yw[3] = __builtin_bit_cast(int, R3);
+    return __builtin_bit_cast(f16x8, yw);
+  };
+  // a new source cell (wave-uniform): fold the finished one, then D1 and U_i = exp(-|x_i - c_S|^2) for this one
+  auto new_cell = [&](const f32x4 cs, int ks) {
+    if (key_s >= 0) fold();
+    key_s = ks;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) D1[c] = (cT[c] - cs[c]) * LOG2E;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      f32x4 dv;
+      if constexpr (!HOLD_D) dv = *reinterpret_cast<const f32x4*>(&dsh[wave][tt][r][0]);
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float df;
+        if constexpr (HOLD_D) df = dl[tt][c] + (cT[c] - cs[c]);
+        else df = dv[c] + (cT[c] - cs[c]);
+        s2 = fmaf(df, df, s2);
+      }
+      U[tt] = kexp2(s2 * -LOG2E);
+    }
+  };
+
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    const int buf = (int)((s - s_begin) & 1);
+    if (s + 1 < s_end) fetch(s + 1);
+    const f32x4* hdr = reinterpret_cast<const f32x4*>(&lds[buf][CMM_HDR_OFF]);
+    const f32x4 cs0 = hdr[0];
+    int ks = __builtin_amdgcn_readfirstlane(__float_as_int(cs0[3]));
+    if (ks >= 0) {  // (pad tiles, key -1, only trail the last source tile)
+      if (ks != key_s) new_cell(cs0, ks);
+      float wb0;
+      f16x8 ya = build(buf, 0, wb0);
+      S0 += wb0;
+      int q = 0;
+      for (;;) {
+        // Software pipeline: A of tile q + 1 is ALWAYS built here, in the basic block of tile q's MFMAs, so
+        // that the VALU works in the shadow of the matrix pipe (TT x 32 cycles).  It is built with this cell's
+        // D1; if tile q + 1 turns out to start another cell (once per ~30 tiles) it is built again below.
+        // There is exactly ONE site of accumulating MFMAs and no branch around it: anything else makes the
+        // compiler copy accumulator registers by the hundred.
+        const int qn = q + 1 < CMM_STAGE_TILES ? q + 1 : q;
+        float wbn;
+        i32x4 yn = __builtin_bit_cast(i32x4, build(buf, qn, wbn));
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ya, xb[tt], acc[tt], 0, 0, 0);
+        // pins the build in THIS block: its only consumer is the "same cell" branch below, and the compiler
+        // would otherwise sink it there, out of the MFMAs' shadow
+        asm volatile("" : "+v"(yn), "+v"(wbn));
+        if constexpr (TT >= 4) {
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002 | 0x100, (32 + TT - 1) / TT, 0);  // its share of the build
+          }
+        }
+        if (++q >= CMM_STAGE_TILES) break;
+        const f32x4 cs = hdr[q];
+        ks = __builtin_amdgcn_readfirstlane(__float_as_int(cs[3]));
+        if (ks < 0) break;
+        if (ks == key_s) {
+          S0 += wbn;
+          ya = __builtin_bit_cast(f16x8, yn);
+        } else {
+          new_cell(cs, ks);
+          float wb1;
+          ya = build(buf, q, wb1);
+          S0 += wb1;
+        }
+      }
+    }
+    if (s + 1 < s_end) commit(buf ^ 1);  // the other buffer was last read before the previous barrier
+    __syncthreads();
+  }
+  if (key_s >= 0) fold();
+
+  const double inv = (double)a.scale[1];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+    if (h == 0) a.part[(int64_t)seg * a.n_slots + (tile0 + tt) * CELL_TILE + r] = outd[tt] * inv;
+}
+
+hipError_t launch_cellmm_gaussian(int TT, const CellmmArgs& args, dim3 grid, hipStream_t stream, const char** kernel_name);
+
+}  // namespace kmvp

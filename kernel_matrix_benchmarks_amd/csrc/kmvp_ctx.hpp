@@ -22,7 +22,7 @@
 namespace kmvp {
 
 // which path's layouts the shared xs / rec buffers hold
-enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2, LAYOUT_CFAST = 3, LAYOUT_CELL = 4, LAYOUT_CELL64 = 5 };
+enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2, LAYOUT_CFAST = 3, LAYOUT_CELL = 4, LAYOUT_CELL64 = 5, LAYOUT_CELLMM = 6 };
 
 struct DevBuf {
   void* p = nullptr;
@@ -117,7 +117,7 @@ struct kmvp_ctx {
   // cell-reduced Gaussian path (kmvp_cell.hpp): cell order of targets / sources, their tiles
   // ([start][count][key] per tile), slot of every target in cell order, target tile centres,
   // segment-reduced sums in cell order
-  DevBuf cell_tperm, cell_sperm, cell_tgrp, cell_sgrp, cell_slot, cell_tmeta, cell_sums, cell_skey, cell_scentre;
+  DevBuf cell_tperm, cell_sperm, cell_tgrp, cell_sgrp, cell_slot, cell_tmeta, cell_sums, cell_skey, cell_scentre, cell_scale;
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
   DevBuf xchg;                  // sharded runs: sums in the canonical unpadded layout [column][N] for the all-reduce
   DevBuf scratch;               // CG vectors / dot products

@@ -6,6 +6,7 @@
 #include <vector>
 #include "kmvp_cell_pack.hpp"
 #include "kmvp_cell64_pack.hpp"
+#include "kmvp_cellmm_pack.hpp"
 #include "kmvp_cfast_pack.hpp"
 #include "kmvp_fast_pack.hpp"
 #include "kmvp_mfma_pack.hpp"
@@ -902,6 +903,106 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   return finish_product(c, (int64_t)NE * N, N, N, E, sig);
 }
 
+// ---- cell form with the sum over the sources in the MFMA accumulator (kmvp_cellmm.hpp): float32, D <= 3,
+// E == 1, plain product / density.  Shares grid, cell order, tile lists and the target layout with cell_kernel.
+
+// log2 of the largest W_j(T) = exp(e_j.(2 D - e_j)) on this grid: |e_a| <= h_a / 2, |D_a| <= g_a h_a
+int cellmm_wlog2(const kmvp_ctx* c) {
+  double arg = 0.0;
+  for (int a = 0; a < c->D; ++a) arg += (double)c->cell_hh[a] * ((double)c->cell_g[a] * c->cell_hh[a]);
+  return (int)std::ceil(arg * 1.4426950408889634);
+}
+
+int run_product_cellmm(kmvp_ctx* c, int sig) {
+  const int D = c->D;
+  const int E = 1;
+  const int64_t N = c->N;
+  const bool small = N < SMALL_PROBLEM_TARGETS;
+  const int TT = c->cell_tt;  // the target tile list was built for it (cell_prepare)
+  const int64_t n_tiles = round_up(c->cell_n_tiles, (int64_t)TT * WAVES_PER_BLOCK);
+  const int64_t n_slots = n_tiles * CELL_TILE;
+  const int64_t tile_blocks = n_tiles / (TT * WAVES_PER_BLOCK);
+  const int64_t m_stages = (c->cell_m_tiles + CMM_STAGE_TILES - 1) / CMM_STAGE_TILES;
+  int rc;
+  CellGrid grid;
+  cell_load_grid(c, grid);
+
+  int segments = choose_segments(c, tile_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, small ? 1 : 2, small);
+  const int64_t seg_stages = (m_stages + segments - 1) / segments;
+  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
+                         c->packed_layout != LAYOUT_CELLMM || c->packed_T != TT;
+  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int* tperm = (const int*)(c->same_points ? c->cell_sperm.p : c->cell_tperm.p);
+  const int* tgrp = (const int*)c->cell_tgrp.p;
+  const int* sgrp = (const int*)c->cell_sgrp.p;
+  if ((rc = ensure(c, c->cell_scale, 64))) return rc;
+  float* scale = (float*)c->cell_scale.p;
+  unsigned* bmax = (unsigned*)c->cell_scale.p + 4;
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_slots * 4 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->cell_tmeta, (size_t)n_tiles * 4 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->cell_slot, (size_t)N * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->rec, (size_t)m_stages * CMM_STAGE_BYTES))) return rc;
+    hipLaunchKernelGGL(pack_cell_targets_kernel, dim3((unsigned)n_tiles), dim3(CELL_TILE), 0, c->stream, x_raw, tperm,
+                       tgrp, tgrp + c->cell_n_tiles, (const unsigned*)(tgrp + 2 * c->cell_n_tiles), c->cell_n_tiles, D,
+                       grid, (float*)c->xs.p, (float*)c->cell_tmeta.p, (int*)c->cell_slot.p);
+    hipLaunchKernelGGL(pack_cellmm_points_kernel, dim3((unsigned)(m_stages * CMM_STAGE_TILES)), dim3(CELL_TILE), 0,
+                       c->stream, (const float*)c->y_raw.p, (const int*)c->cell_sperm.p, sgrp, sgrp + c->cell_m_tiles,
+                       (const unsigned*)(sgrp + 2 * c->cell_m_tiles), c->cell_m_tiles, D, grid, (unsigned char*)c->rec.p);
+  }
+  if (sig_stale) {  // only the signal part of the image: max |b| -> sigma_b -> b sigma_b in tile order
+    const float* b = sig == SIG_DENSITY ? (const float*)nullptr : (const float*)c->b_raw.p;
+    HIP_TRY(c, hipMemsetAsync(bmax, 0, sizeof(unsigned), c->stream));
+    if (b)
+      hipLaunchKernelGGL(cellmm_absmax_kernel, dim3((unsigned)std::min<int64_t>(1024, (c->M + 255) / 256)), dim3(256), 0,
+                         c->stream, b, c->M, bmax);
+    hipLaunchKernelGGL(cellmm_scale_kernel, dim3(1), dim3(1), 0, c->stream, (const unsigned*)bmax, cellmm_wlog2(c),
+                       b ? 0 : 1, scale);
+    hipLaunchKernelGGL(pack_cellmm_signal_kernel, dim3((unsigned)(m_stages * CMM_STAGE_TILES)), dim3(CELL_TILE), 0,
+                       c->stream, b, (const int*)c->cell_sperm.p, sgrp, sgrp + c->cell_m_tiles, c->cell_m_tiles,
+                       (const float*)scale, (unsigned char*)c->rec.p);
+  }
+  HIP_TRY(c, hipGetLastError());
+  c->packed_points_ver = c->points_ver;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_kernel = K_GAUSSIAN;
+  c->packed_sig = sig;
+  c->packed_layout = LAYOUT_CELLMM;
+  c->packed_T = TT;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * n_slots * sizeof(double)))) return rc;
+  CellmmArgs a;
+  a.xd = (const float*)c->xs.p;
+  a.tmeta = (const float*)c->cell_tmeta.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.scale = scale;
+  a.part = (double*)c->part.p;
+  a.n_slots = n_slots;
+  a.m_stages = m_stages;
+  a.seg_stages = seg_stages;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  const dim3 grid_dim((unsigned)(tile_blocks * segments));
+  HIP_TRY(c, mark(c, 0));
+  hipError_t le = launch_cellmm_gaussian(TT, a, grid_dim, c->stream, &c->last_kernel_name);
+  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2, 4 or 8");
+  HIP_TRY(c, le);
+  HIP_TRY(c, mark(c, 1));
+
+  // ---- epilogue: segments -> sums in the caller's order, [all-reduce over the source shards]
+  if ((rc = ensure(c, c->sums, (size_t)N * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->cell_sums, (size_t)n_slots * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(n_slots)), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->cell_sums.p, n_slots, segments);
+  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for(N)), dim3(256), 0, c->stream,
+                     (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, 1);
+  HIP_TRY(c, hipGetLastError());
+  return finish_product(c, N, N, N, E, sig);
+}
+
 // ---- float64 cell path (kmvp_cell64.hpp): Gaussian, D <= 3, E == 1, plain product ----------------------
 
 // Grid, cell order, target tiles of 64 and the list of source cells for the current points.
@@ -1152,7 +1253,7 @@ int prepare_points(kmvp_ctx* c, int kernel) {
   if (c->dtype == KMVP_F32) {
     const float sc = scale_for<float>(kernel);
     const bool global_ok = c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
-    if (c->opt_fast == 3 || (global_ok && big))
+    if (c->opt_fast >= 3 || (global_ok && big))
       return cell_prepare(c, c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : 0));
   } else if (c->dtype == KMVP_F64) {
     if (c->opt_fast == 3 || big) return cell64_prepare(c);
@@ -1235,11 +1336,18 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     // cell_kernel: exp() range-reduced by grid cells, the polynomial remainder on the matrix cores
     // (Gaussian, D <= 3).  auto: when the clouds fill the cells well enough that padding stays small.
     if (kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->async_product &&
-        (c->opt_fast == 3 || (c->opt_fast < 0 && global_ok && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
+        (c->opt_fast >= 3 || (c->opt_fast < 0 && global_ok && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
       const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : 0);  // 0: by the padding
       int rc = cell_prepare(c, TT);
       if (rc) return rc;
-      if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) return run_product_cell(c, sig);
+      if (c->cell_state == 1 && (c->opt_fast >= 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) {
+        // cellmm_kernel (weights in the operand, sum in the accumulator) where its f16 operands have the range:
+        // plain products and densities on clouds inside the radius rule; cell_kernel otherwise (normalised
+        // rows, wide clouds) or on request (fast_sqdists = 4)
+        if (c->opt_fast != 4 && sig != SIG_NORM && global_ok && cellmm_wlog2(c) <= CMM_MAX_WLOG2)
+          return run_product_cellmm(c, sig);
+        return run_product_cell(c, sig);
+      }
     }
     if (c->opt_fast == 1 || (c->opt_fast < 0 && global_ok)) return run_product_fast(c, kernel, sig);
     if (centred_ok && (c->opt_fast == 2 || c->opt_fast < 0)) return run_product_cfast(c, kernel, sig);
