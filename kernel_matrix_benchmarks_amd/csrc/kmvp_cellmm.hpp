@@ -2,9 +2,8 @@
 //
 // cell_kernel (kmvp_cell.hpp) takes the remainder polynomial of the range-reduced exponential from one
 // bf16 MFMA per 32 x 32 pairs and still spends ONE VALU FMA PER PAIR on weighting it with W_j b_j and
-// summing over the sources: 22.5 VALU instructions per 32 x 32 tile pair, VALU issue saturated, the matrix
-// pipe 37 % busy (profiles/r01_gaussian_1e6_f32_cell_kernel_sq_counters.txt).  Here the weight moves INTO
-// the source operand and the sum INTO the MFMA's accumulator:
+// summing over the sources: 22.5 VALU instructions per 32 x 32 tile pair, the VALU saturated, the matrix
+// pipe 37 % busy.  Here the weight moves INTO the source operand and the sum INTO the MFMA's accumulator:
 //
 //     exp(-|x_i - y_j|^2) b_j = U_i(S) * [ W_j(T) b_j * exp(t_ij) ] ,  t_ij = 2 d_i.e_j ,  |t| <= 0.016
 //         (x_i = c_T + d_i, y_j = c_S + e_j, D = c_T - c_S, U_i(S) = exp(-|x_i - c_S|^2),
@@ -14,30 +13,36 @@
 // with the fifteen monomial pairs of t + t^2/2 as the K = 16 contraction index of ONE
 // v_mfma_f32_32x32x16_f16 per 32 sources x 32 targets, whose fp32 accumulator (row = source, column =
 // target) is carried from source tile to source tile of a source cell:  acc += A_tile(T) x B.  The VALU
-// touches a pair of tiles only to rebuild A for the wave's target cell -- ~32 instructions per source tile,
-// shared by the TT = 8 target tiles of the wave, i.e. 4 per tile pair instead of 22.5 -- and, once per
-// (target tile, source CELL), to fold the accumulator: 15 adds over its 16 rows, one cross-half add,
-// times U_i(S), into an fp64 sum.  The constant term W_j b_j of the bracket does not depend on the target
-// inside a cell: it is summed per lane in fp32 as the rows of A are built and joins the accumulator's row
-// sum at the fold (exact in fp32, where an f16 operand would have needed three more slots).  Every pair is
-// still evaluated -- sixteen multiply-adds per pair on the matrix pipe -- and nothing is truncated in
-// space.
+// touches a pair of tiles only to rebuild A for the wave's target cell -- ~27 instructions per source tile
+// and lane, shared by the TT = 8 target tiles of the wave: 3.4 per tile pair instead of 22.5 -- and, once per
+// (target tile, source CELL), to fold the accumulator: its 16 rows summed, one cross-half add, times
+// U_i(S), into an fp64 sum.  The constant term
+// W_j b_j of the bracket does not depend on the target inside a cell: it is summed per lane in fp32 as the
+// rows of A are built and joins the accumulator's row sum at the fold (exact in fp32, where an f16 operand
+// would have needed three more slots).  Every pair is still evaluated -- sixteen multiply-adds per pair on
+// the matrix pipe -- and nothing is truncated in space.
 //
 // Precision.  f16 operands (11 significant bits), fp32 products and accumulation.  Slots (k = 8 h + j for
-// lane half h, register pair j/2):
-//     h = 0:  d_xh e'_xh, d_yh e'_yh, d_xh e'_xm, d_yh e'_ym, d_xm e'_xh, d_ym e'_yh, (d_x^2/2)(e'_x f_x), (d_y^2/2)(e'_y f_y)
-//     h = 1:  d_zh e'_zh, d_xd_z(e'_x f_z), d_zh e'_zm, d_xd_z(rest), d_zm e'_zh, d_yd_z(e'_y f_z), (d_z^2/2)(e'_z f_z), d_xd_y(e'_x f_y)
-// with f = 2 e, e' = f W b and v = v_h + v_m the two-way f16 split (22 bits).  Linear terms: dropped
-// d_m e'_m <= 2^-22 |t| = 4e-9; quadratic terms (<= 1.3e-4) in one f16 product each: <= 1.3e-7 in the worst
-// corner, ~1e-8 typically; truncation t^3/6 as in cell_kernel (<= 6.8e-7 corner to corner, ~1e-8 typical).
-// Operands are scaled by powers of two into the normal range of f16 (targets x 2^6; the signal by
-// sigma_b = 2^(15 - ceil(log2(0.104 Wmax max|b|))), kmvp_cellmm_pack.hpp), undone exactly at the store.
+// lane half h, register pair j/2), with f = 2 e, e' = f W b and v = v_h + v_m the two-way f16 split:
+//     h = 0:  d_xh e'_xh, d_yh e'_yh, d_xh e'_xm, d_yh e'_ym, d_xm e'_xh, d_ym e'_yh, (d_x^2/2)(f_x^2 Wb), (d_y^2/2)(f_y^2 Wb)
+//     h = 1:  d_zh e'_zh, d_xd_z(f_x f_z Wb)_h, d_zh e'_zm, d_xd_z(f_x f_z Wb)_m, d_zm e'_zh, d_yd_z(f_y f_z Wb), (d_z^2/2)(f_z^2 Wb), d_xd_y(f_x f_y Wb)
+// Linear terms carry 22 bits: dropped d_m e'_m <= 2^-22 |t| = 4e-9; quadratic terms (<= 1.3e-4) in one f16
+// product each: <= 1.3e-7 in the worst corner, ~1e-8 typically; truncation t^3/6 as in cell_kernel (<= 6.8e-7
+// corner to corner, ~1e-8 typical).  Operands are scaled by powers of two into the normal range of f16
+// (targets x 2^6; the signal by sigma_b = 2^(15 - ceil(log2(0.104 Wmax max|b|))), kmvp_cellmm_pack.hpp),
+// undone exactly at the store.
 //
 // Mapping: a wave owns TT target tiles of ONE cell (cells are padded to multiples of TT tiles); a workgroup
 // of 4 waves shares LDS stages of 12 source tiles (32 x (f_x, f_y, f_z, -|e|^2 log2 e), 32 x b, cell
-// header) prefetched through registers, double buffered, one barrier per stage.  TT = 8: 128 accumulator registers
-// per lane, two waves per SIMD -- while one wave's eight MFMAs (256 matrix-pipe cycles) run, the other
-// builds its next A.
+// header) prefetched through registers, double buffered, one barrier per stage.  TT = 8: 128 accumulator
+// registers per lane, two waves per SIMD.
+//
+// Roof.  The kernel is bound by the matrix pipe, and the pipe by POWER: tools/mfma_stream.hip sustains
+// 2.48 PFLOP/s (32.4 cycles per MFMA at 2.4 GHz) on zero operands and 1.50-1.61 PFLOP/s (50-53 nominal
+// cycles) on random f16 operands -- the chip sits at its power limit and the clock falls to ~2.0 GHz.  With
+// the operand build and the per-tile bookkeeping removed from this kernel's loop (timing-only experiment)
+// the same launch takes 25.4 ms against 26.0-26.9 ms complete: the VALU work is hidden, what remains is
+// the MFMA stream itself (1.30 PFLOP/s, 0.52 of the nominal 2.5, 0.83 of what random data sustains).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -103,8 +108,11 @@ __device__ __forceinline__ f16x8 cellmm_target_operand(const f32x4 d, int h) {
   return out;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int TT>
-__global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(TT >= 8 ? 2 : 1))) cellmm_kernel(const CellmmArgs a) {
+__global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(TT >= 8 ? 2 : 1)))
+cellmm_kernel(const CellmmArgs a) {
   constexpr int SB = CMM_STAGE_BYTES;
   constexpr int PIECES = SB / (16 * BLOCK_THREADS);
   constexpr float LOG2E = 1.4426950408889634f;
@@ -187,41 +195,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       const f32x16 d = acc[tt];
-      float v0 = (d[0] + d[1]) + (d[2] + d[3]);
-      float v1 = (d[4] + d[5]) + (d[6] + d[7]);
-      float v2 = (d[8] + d[9]) + (d[10] + d[11]);
-      float v3 = (d[12] + d[13]) + (d[14] + d[15]);
-      float v = (v0 + v1) + (v2 + v3);
+      // the 16 rows with packed adds: 4 + 2 + 1 v_pk_add_f32 and one v_add_f32
+      f32x2 p0 = f32x2{d[0], d[1]} + f32x2{d[2], d[3]};
+      f32x2 p1 = f32x2{d[4], d[5]} + f32x2{d[6], d[7]};
+      f32x2 p2 = f32x2{d[8], d[9]} + f32x2{d[10], d[11]};
+      f32x2 p3 = f32x2{d[12], d[13]} + f32x2{d[14], d[15]};
+      p0 = p0 + p1;
+      p2 = p2 + p3;
+      p0 = p0 + p2;
+      float v = p0[0] + p0[1];
       v += __shfl_xor(v, 32);
       outd[tt] += (double)(U[tt] * (v + s0));
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc[tt][k] = 0.f;  // the next source cell starts from zero
     }
     S0 = 0.f;
-  };
-
-  // A = psi_k(e_j) W_j(T) b_j of source tile q for source row r, k-half h (~30 VALU instructions); wb = W_j b_j
-  auto build = [&](int buf, int q, float& wb) -> f16x8 {
-    const f32x4 ef = *reinterpret_cast<const f32x4*>(&lds[buf][CMM_E_OFF + (q * CELL_TILE + r) * 16]);
-    const float bq = *reinterpret_cast<const float*>(&lds[buf][CMM_B_OFF + (q * CELL_TILE + r) * 4]);
-    const float arg = fmaf(ef[0], D1[0], fmaf(ef[1], D1[1], fmaf(ef[2], D1[2], ef[3])));
-    wb = kexp2(arg) * bq;
-    const float px = ef[0] * wb, py = ef[1] * wb, pz = ef[2] * wb;  // e' = f W b (x sigma_b)
-    const float u1 = h ? pz : px;                  // split: x | z
-    const float u2 = h ? px * ef[2] : py;          // split: y | the x z monomial
-    const f16x2 R0 = cellmm_pk(u1, u2);
-    const float c1 = (float)R0[0], c2 = (float)R0[1];
-    const f16x2 R1 = cellmm_pk(u1 - c1, u2 - c2);
-    const float q1 = u1 * (h ? ef[2] : ef[0]);     // x x | z z
-    const float v2 = (h ? px : py) * ef[1];        // y y | x y
-    const f16x2 R3 = cellmm_pk(q1, v2);
-    const f16x2 R2 = cellmm_pk(c1, h ? py * ef[2] : c2);  // (x_h, y_h) | (z_h, y z)
-    i32x4 yw;
-    yw[0] = __builtin_bit_cast(int, R0);
-    yw[1] = __builtin_bit_cast(int, R1);
-    yw[2] = __builtin_bit_cast(int, R2);
-    yw[3] = __builtin_bit_cast(int, R3);
-    return __builtin_bit_cast(f16x8, yw);
   };
   // a new source cell (wave-uniform): fold the finished one, then D1 and U_i = exp(-|x_i - c_S|^2) for this one
   auto new_cell = [&](const f32x4 cs, int ks) {
@@ -248,50 +236,46 @@ __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per
   for (int64_t s = s_begin; s < s_end; ++s) {
     const int buf = (int)((s - s_begin) & 1);
     if (s + 1 < s_end) fetch(s + 1);
-    const f32x4* hdr = reinterpret_cast<const f32x4*>(&lds[buf][CMM_HDR_OFF]);
-    const f32x4 cs0 = hdr[0];
-    int ks = __builtin_amdgcn_readfirstlane(__float_as_int(cs0[3]));
-    if (ks >= 0) {  // (pad tiles, key -1, only trail the last source tile)
-      if (ks != key_s) new_cell(cs0, ks);
-      float wb0;
-      f16x8 ya = build(buf, 0, wb0);
-      S0 += wb0;
-      int q = 0;
-      for (;;) {
-        // Software pipeline: A of tile q + 1 is ALWAYS built here, in the basic block of tile q's MFMAs, so
-        // that the VALU works in the shadow of the matrix pipe (TT x 32 cycles).  It is built with this cell's
-        // D1; if tile q + 1 turns out to start another cell (once per ~30 tiles) it is built again below.
-        // There is exactly ONE site of accumulating MFMAs and no branch around it: anything else makes the
-        // compiler copy accumulator registers by the hundred.
-        const int qn = q + 1 < CMM_STAGE_TILES ? q + 1 : q;
-        float wbn;
-        i32x4 yn = __builtin_bit_cast(i32x4, build(buf, qn, wbn));
+    const unsigned char* base = &lds[buf][0];
+    // running per-lane read addresses of the two streams (one v_add each per tile)
+    const unsigned char* p_ef = base + CMM_E_OFF + r * 16;
+    const unsigned char* p_b = base + CMM_B_OFF + r * 4;
+    const f32x4* hdr = reinterpret_cast<const f32x4*>(base + CMM_HDR_OFF);
+#pragma unroll 1
+    for (int q = 0; q < CMM_STAGE_TILES; ++q) {
+      const f32x4 cs = hdr[q];
+      const int ks = __builtin_amdgcn_readfirstlane(__float_as_int(cs[3]));
+      if (ks < 0) break;                    // pad tiles (key -1) only trail the last source tile (wave-uniform)
+      if (ks != key_s) new_cell(cs, ks);    // wave-uniform, once per ~30 tiles
+      // ---- A = psi_k(e_j) W_j(T) b_j for source row r, k-half h: ~27 VALU instructions
+      const f32x4 ef = *reinterpret_cast<const f32x4*>(p_ef);
+      const float bq = *reinterpret_cast<const float*>(p_b);
+      p_ef += CELL_TILE * 16;
+      p_b += CELL_TILE * 4;
+      // the lane half's five monomial factors: every entry of A is then ONE product a_k * (W_j b_j)
+      const f32x4 a14 = h ? f32x4{ef[2], ef[0] * ef[2], ef[2] * ef[2], ef[0] * ef[1]}
+                          : f32x4{ef[0], ef[1], ef[0] * ef[0], ef[1] * ef[1]};
+      const float a5 = h ? ef[1] * ef[2] : ef[1];
+      const float arg = fmaf(ef[0], D1[0], fmaf(ef[1], D1[1], fmaf(ef[2], D1[2], ef[3])));
+      const float wb = kexp2(arg) * bq;  // W_j b_j (x sigma_b); v_exp_f32 runs beside the MFMAs
+      S0 += wb;
+      const float u1 = a14[0] * wb, u2 = a14[1] * wb;   // x, y | z, x z   (two-way split below)
+      const f16x2 R0 = cellmm_pk(u1, u2);
+      const float c1 = (float)R0[0], c2 = (float)R0[1];
+      const f16x2 R1 = cellmm_pk(u1 - c1, u2 - c2);
+      const f16x2 R3 = cellmm_pk(a14[2] * wb, a14[3] * wb);  // x x, y y | z z, x y
+      const f16x2 R2 = cellmm_pk(c1, a5 * wb);               // (x_h, y_h) | (z_h, y z)
+      i32x4 yw;
+      yw[0] = __builtin_bit_cast(int, R0);
+      yw[1] = __builtin_bit_cast(int, R1);
+      yw[2] = __builtin_bit_cast(int, R2);
+      yw[3] = __builtin_bit_cast(int, R3);
+      const f16x8 ya = __builtin_bit_cast(f16x8, yw);
+      // ONE site of accumulating MFMAs and no branch around it (anything else makes the compiler copy
+      // accumulator registers by the hundred): the empty tiles that pad a cell to TT tiles run too, their
+      // columns are never read back
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ya, xb[tt], acc[tt], 0, 0, 0);
-        // pins the build in THIS block: its only consumer is the "same cell" branch below, and the compiler
-        // would otherwise sink it there, out of the MFMAs' shadow
-        asm volatile("" : "+v"(yn), "+v"(wbn));
-        if constexpr (TT >= 4) {
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002 | 0x100, (32 + TT - 1) / TT, 0);  // its share of the build
-          }
-        }
-        if (++q >= CMM_STAGE_TILES) break;
-        const f32x4 cs = hdr[q];
-        ks = __builtin_amdgcn_readfirstlane(__float_as_int(cs[3]));
-        if (ks < 0) break;
-        if (ks == key_s) {
-          S0 += wbn;
-          ya = __builtin_bit_cast(f16x8, yn);
-        } else {
-          new_cell(cs, ks);
-          float wb1;
-          ya = build(buf, q, wb1);
-          S0 += wb1;
-        }
-      }
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ya, xb[tt], acc[tt], 0, 0, 0);
     }
     if (s + 1 < s_end) commit(buf ^ 1);  // the other buffer was last read before the previous barrier
     __syncthreads();

@@ -133,12 +133,24 @@ def test_cell_kernel_matches_reference(case, expected):
     y, x, b = golden_cases.make_inputs(case)
     truth = expected[f"{case['name']}/f64"]
     ref32 = expected[f"{case['name']}/f32"].astype(np.float64)
-    for tiles in (1, 2, 4, 8):
-        got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists="cells", fast_tiles=tiles)
-        if not (case["normalize_rows"] and case["density_estimation"]):
-            assert extra["device_kernel"] == "cell_kernel"
-        tol = max(TOL32, 2 * rel_err(ref32, truth))
-        assert rel_err(got, truth) <= tol, (tiles, rel_err(got, truth), tol)
+    for form in ("cells", "cells-valu"):
+        for tiles in (1, 2, 4, 8):
+            got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists=form, fast_tiles=tiles)
+            if not (case["normalize_rows"] and case["density_estimation"]):
+                # "cells": cellmm_kernel (sum over the sources in the MFMA accumulator) for plain products and
+                # densities on clouds inside the radius rule, cell_kernel otherwise; "cells-valu": always cell_kernel
+                allowed = ("cell_kernel",) if form == "cells-valu" or case["normalize_rows"] else ("cellmm_kernel", "cell_kernel")
+                assert extra["device_kernel"] in allowed, (form, extra)
+                CELL_KERNELS_SEEN.add(extra["device_kernel"])
+            tol = max(TOL32, 2 * rel_err(ref32, truth))
+            assert rel_err(got, truth) <= tol, (form, tiles, rel_err(got, truth), tol)
+
+
+CELL_KERNELS_SEEN = set()
+
+
+def test_golden_cases_reached_both_cell_kernels():
+    assert CELL_KERNELS_SEEN == {"cellmm_kernel", "cell_kernel"}, CELL_KERNELS_SEEN
 
 
 def test_cell_kernel_shapes_offsets_and_auto_policy():
@@ -163,13 +175,17 @@ def test_cell_kernel_shapes_offsets_and_auto_policy():
                                    source_signal=None if dens else b.astype(np.float64), normalize_rows=norm,
                                    density_estimation=dens)
         case = dict(kernel="gaussian", D=D, normalize_rows=norm)
+        cell_name = "cell_kernel" if norm else "cellmm_kernel"  # normalised rows: two sums, cell_kernel
         got, extra = run_plugin(case, y, x, None if dens else b, "float32", fast_sqdists="cells")
-        assert extra["device_kernel"] == "cell_kernel", extra
+        assert extra["device_kernel"] == cell_name, extra
         assert rel_err(got[rows], want) <= TOL32, (case_no, rel_err(got[rows], want))
+        valu, extra = run_plugin(case, y, x, None if dens else b, "float32", fast_sqdists="cells-valu")
+        assert extra["device_kernel"] == "cell_kernel", extra
+        assert rel_err(valu[rows], want) <= TOL32, (case_no, rel_err(valu[rows], want))
         auto, extra = run_plugin(case, y, x, None if dens else b, "float32")
-        # clouds that fill the cells go to the cell kernel by themselves; 4e4 points in the unit cube
+        # clouds that fill the cells go to the cell kernels by themselves; 4e4 points in the unit cube
         # (40 per cell of side 0.103: more than 30 % of the tile slots would be padding) stay with fast_kernel
-        assert extra["device_kernel"] == ("fast_kernel" if case_no == 4 else "cell_kernel"), (case_no, extra)
+        assert extra["device_kernel"] == ("fast_kernel" if case_no == 4 else cell_name), (case_no, extra)
         assert rel_err(auto[rows], want) <= TOL32, (case_no, rel_err(auto[rows], want))
 
 
@@ -260,10 +276,11 @@ def test_cell_kernel_on_clustered_clouds():
     rows = rs.choice(len(x), size=400, replace=False)
     want = kmvp_oracle.product(kernel="gaussian", source_points=y.astype(np.float64), target_points=x[rows].astype(np.float64),
                                source_signal=b.astype(np.float64))
-    for tiles in (1, 4, 8):
-        got, extra = run_plugin(dict(kernel="gaussian", D=3), y, x, b, "float32", fast_sqdists="cells", fast_tiles=tiles)
-        assert extra["device_kernel"] == "cell_kernel"
-        assert rel_err(got[rows], want) <= TOL32, (tiles, rel_err(got[rows], want))
+    for form, kname in (("cells", "cellmm_kernel"), ("cells-valu", "cell_kernel")):
+        for tiles in (1, 4, 8):
+            got, extra = run_plugin(dict(kernel="gaussian", D=3), y, x, b, "float32", fast_sqdists=form, fast_tiles=tiles)
+            assert extra["device_kernel"] == kname
+            assert rel_err(got[rows], want) <= TOL32, (form, tiles, rel_err(got[rows], want))
     same, extra = run_plugin(dict(kernel="gaussian", D=3, normalize_rows=True), y, None, b, "float32", fast_sqdists="cells")
     rows = rs.choice(len(y), size=400, replace=False)
     want = kmvp_oracle.product(kernel="gaussian", source_points=y.astype(np.float64), target_points=y[rows].astype(np.float64),
@@ -275,10 +292,11 @@ def test_cell_paths_follow_new_points_and_signals_in_one_context():
     """One context, points and signals replaced in turn (float32 and float64 cell paths): the cell order belongs
     to a points version, the source image to a signal version -- neither may be reused across an upload."""
     rs = np.random.RandomState(31)
-    for dtype, npdt, tol, kname in ((_lib.KMVP_F32, np.float32, TOL32, "cell_kernel"), (_lib.KMVP_F64, np.float64, TOL64, "cell64_kernel")):
+    for dtype, npdt, tol, kname in ((_lib.KMVP_F32, np.float32, TOL32, "cellmm_kernel"), (_lib.KMVP_F32, np.float32, TOL32, "cell_kernel"),
+                                    (_lib.KMVP_F64, np.float64, TOL64, "cell64_kernel")):
         ctx = _lib.Context(0)
         try:
-            ctx.set_option("fast_sqdists", 3)
+            ctx.set_option("fast_sqdists", 4 if kname == "cell_kernel" else 3)
             for n, side in ((40000, 0.4), (36000, 0.7), (40000, 0.4)):
                 y = (rs.rand(n, 3) * side).astype(npdt)
                 ctx.set_points(y, None, dtype)
@@ -501,11 +519,11 @@ def test_matrix_core_kernels_reproducible_and_tile_count_independent():
 
     for kernel, fast, kname in (("gaussian", 1, "fast_kernel"), ("inverse-distance", 2, "cfast_kernel"),
                                 ("absolute-exponential", 2, "cfast_kernel"), ("gaussian", 2, "cfast_kernel"),
-                                ("gaussian", 3, "cell_kernel")):
+                                ("gaussian", 3, "cellmm_kernel"), ("gaussian", 4, "cell_kernel")):
         base, name = product(kernel, fast, 1)
         assert name == kname
         scale = np.max(np.abs(base))
-        for tiles in (2, 4, 8):  # 8: cell_kernel only, the others clamp to 4
+        for tiles in (2, 4, 8):  # 8: the cell kernels only, the others clamp to 4
             other, _ = product(kernel, fast, tiles)
             assert np.max(np.abs(other - base)) <= 5e-6 * scale, (kernel, kname, tiles, np.max(np.abs(other - base)) / scale)
 
@@ -631,7 +649,8 @@ def test_single_rank_rccl_communicator():
     y, b = kmvp_oracle.uniform_cube(n, 3)
     cases = [("gaussian", True, _lib.KMVP_F32, 0, "lowd_kernel"), ("gaussian", True, _lib.KMVP_F32, 1, "fast_kernel"),
              ("inverse-distance", False, _lib.KMVP_F32, 2, "cfast_kernel"),
-             ("gaussian", False, _lib.KMVP_F32, 3, "cell_kernel"), ("gaussian", True, _lib.KMVP_F32, 3, "cell_kernel"),
+             ("gaussian", False, _lib.KMVP_F32, 3, "cellmm_kernel"), ("gaussian", False, _lib.KMVP_F32, 4, "cell_kernel"),
+             ("gaussian", True, _lib.KMVP_F32, 3, "cell_kernel"),
              ("gaussian", False, _lib.KMVP_F64, 3, "cell64_kernel"),
              ("absolute-exponential", True, _lib.KMVP_F64, 0, "lowd_kernel")]
     for kernel, norm, dtype, fast, kname in cases:
@@ -811,8 +830,12 @@ def test_config2_cell_kernel_on_all_rows_against_the_float64_difference_form():
         algo.fit()
         algo.prepare_query(source_signal=b)
         algo.query()
-        assert algo.device_kernel == "cell_kernel"  # what auto picks at the headline shape
+        assert algo.device_kernel == "cellmm_kernel"  # what auto picks at the headline shape
         cells = algo.get_result()
+        algo.set_query_arguments(fast_sqdists=4)
+        algo.query()
+        assert algo.device_kernel == "cell_kernel"
+        cells_valu = algo.get_result()
         algo.set_query_arguments(fast_sqdists=0)
         algo.query()
         assert algo.device_kernel == "lowd_kernel"
@@ -821,9 +844,11 @@ def test_config2_cell_kernel_on_all_rows_against_the_float64_difference_form():
         algo.done()
     scale = np.max(np.abs(truth))
     e_cell = np.max(np.abs(cells - truth)) / scale
+    e_valu = np.max(np.abs(cells_valu - truth)) / scale
     e_diff = np.max(np.abs(diff - truth)) / scale
-    print(f"config 2, all 1e6 rows vs float64: cell form {e_cell:.2e}, float32 difference form {e_diff:.2e}")
-    assert e_cell <= 1e-6, e_cell   # measured 4-6e-7: every row, not a sample
+    print(f"config 2, all 1e6 rows vs float64: cellmm_kernel {e_cell:.2e}, cell_kernel {e_valu:.2e}, float32 difference form {e_diff:.2e}")
+    assert e_cell <= 1e-6, e_cell   # measured 6-8e-7: every row, not a sample
+    assert e_valu <= 1e-6, e_valu
     assert e_diff <= TOL32, e_diff
 
 
@@ -856,7 +881,10 @@ def test_cell_kernel_worst_case_placement_in_opposite_cell_corners():
     b = np.abs(rs.randn(n, 1)) + 0.5  # one sign: truncation errors (all of one sign for parallel d, e) cannot cancel
     want = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=np.arange(n))  # float64, all rows
     got, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32", fast_sqdists="cells")
+    assert extra["device_kernel"] == "cellmm_kernel"
+    got_valu, extra = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32", fast_sqdists="cells-valu")
     assert extra["device_kernel"] == "cell_kernel"
+    assert rel_err(got_valu, want) <= 1.5e-6, rel_err(got_valu, want)
     ref, extra0 = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32", fast_sqdists=False)
     assert extra0["device_kernel"] == "lowd_kernel"
     e_cell, e_diff = rel_err(got, want), rel_err(ref, want)
@@ -866,7 +894,8 @@ def test_cell_kernel_worst_case_placement_in_opposite_cell_corners():
     # whatever the plugin picks by itself on this cloud stays inside the tolerance as well
     auto, extra_auto = run_plugin(dict(kernel="gaussian", D=3), y, None, b, "float32")
     assert rel_err(auto, want) <= TOL32, extra_auto
-    print(f"worst-case placement: cell form {e_cell:.2e}, difference form {e_diff:.2e}, auto = {extra_auto['device_kernel']}")
+    print(f"worst-case placement: cellmm_kernel {e_cell:.2e}, cell_kernel {rel_err(got_valu, want):.2e}, difference form {e_diff:.2e}, "
+          f"auto = {extra_auto['device_kernel']}")
 
 
 def test_config4_inverse_distance_one_of_eight_shards_at_full_size():
@@ -1009,7 +1038,7 @@ def test_runner_drives_the_headline_dataset_under_its_reference_name(tmp_path):
     assert np.max(np.abs(truth[rows] - want)) / np.max(np.abs(want)) <= TOL64
     a32, r32 = by_name["MI355XProduct(float32)"]
     a64, r64 = by_name["MI355XProduct(float64)"]
-    assert a32["device_kernel"] == "cell_kernel" and a64["device_kernel"] == "cell64_kernel"
+    assert a32["device_kernel"] == "cellmm_kernel" and a64["device_kernel"] == "cell64_kernel"
     assert metrics.relative_max_error(r32, truth) <= TOL32 and metrics.relative_max_error(r64, truth) <= TOL64
     assert a32["query_time"] < 0.2 and a32["build_time"] < 0.2 and a32["run_count"] == 2
 

@@ -8,6 +8,8 @@ which = sys.argv[1]
 n = 1000000 if which == "f32" else 200000
 rs = np.random.RandomState(n + 3)
 y = rs.rand(n, 3); b = rs.randn(n, 1)
+if os.environ.get("KMVP_ZERO_B"):
+    b[:] = 0
 for fast in ((3,) if which == "f32" else (3, 0)):
     ctx = _lib.Context(0)
     ctx.set_option("fast_sqdists", fast)
