@@ -1,105 +1,199 @@
 #!/usr/bin/env python3
-"""Headline benchmark: point-pair interactions per second of the on-the-fly kernel
-matrix-vector product on MI355X.
+"""Benchmark of the on-the-fly kernel matrix-vector product on MI355X: point-pair interactions per second.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|4shard|5]
 
-Workload (BASELINE.json configs[1]): Gaussian product, uniform points in the unit
-cube (the reference's ``uniform_cube`` recipe, datasets.py:256-266, seed n+D),
-N = M = 1e6, D = 3, E = 1, float32.  One "step" = one full product a = K b
-(1e12 point pairs) with the points and the signal already resident in HBM: exactly
-what the harness times around ``query()`` (runner.py:138-140); ``fit()`` only sorts the
-points into grid cells (~3 ms, once), so query time ~ total time.
+``--config`` names a BASELINE.json config (default 2, the one the headline metric is quoted on):
 
-With N > 1 GPUs (launched by ``python -m torch.distributed.run``, one rank per GPU)
-the M sources are sharded over the ranks and the (N, E) partial sums are summed by
-one RCCL all-reduce inside every step: total work is fixed -> "scaling": "strong".
+  2       Gaussian product, uniform-3D (the reference's ``uniform_cube`` recipe, datasets.py:256-266, seed n+D),
+          N = M = 1e6, E = 1, float32.  One step = one product a = K b (1e12 pairs), points and signal resident
+          in HBM: what the harness times around ``query()`` (runner.py:138-140).
+  3       exp(-r) attention (row-normalised), D = 64, N = M = 65536, E = 64, bf16 MFMA tiles; points scaled by
+          1/sqrt(D).  One step = one normalised product.
+  4       inverse-distance product, uniform-3D, N = M = 1e7, E = 1, float32, the sources sharded over the ranks
+          with ONE RCCL all-reduce of the (N, E) sums per step (BASELINE runs it on 8 GPUs).
+  4shard  what one of those 8 ranks computes, on one GPU without a communicator: all 1e7 targets x its 1.25e6
+          sources (global zero rule through j_offset / M_total).
+  5       Gaussian solver K b = a, N = M = 1e5, D = 3, float64, CG with the HIP matvec as operator, to a
+          relative residual of 1e-6.  One step = one solve; pairs = (iterations + 1 products) x N^2.
 
-Rank 0 prints ONE JSON line.  ``roofline`` describes the dominant kernel
-(lowd_kernel) from HIP-event timings of every timed launch; ``cpu_baseline`` is the
-C/OpenMP restatement of the reference arithmetic (oracle/, test infrastructure)
-timed on this box's host cores on a bounded row sample of the same workload.
+With N > 1 GPUs (launched by ``python -m torch.distributed.run``, one rank per GPU) the M sources are sharded
+over the ranks and the (N, E) partial sums are summed by one RCCL all-reduce inside every step: total work is
+fixed -> "scaling": "strong".  Rank 0 prints ONE JSON line.
+
+``roofline`` describes the dominant kernel from HIP-event timings of every timed launch (events on the library's
+own stream, include/kmvp.h ``kmvp_last_kernel_ms``): ``achieved`` = ALGORITHMIC flops per launch (per-pair
+figure x pairs, no padding) / average kernel time; ``frac_basis`` says which unit's peak ``peak`` is and why;
+``traffic`` is HBM-side bytes per launch from a rocprofv3 PMC run of the same workload (``traffic_source``
+names the committed file; it is NOT measured in this run, and null when no profile of this kernel exists).
+``cpu_baseline`` is test infrastructure timed on this box's host cores: ``port`` = the C/OpenMP restatement of
+the reference's arithmetic (oracle/kmvp_oracle.c) on a bounded row sample of the SAME workload; ``dense`` = the
+numpy restatement of what the reference itself does (materialise K in fit(), then ``K @ b`` in query():
+bruteforce.py:113-153) at the sizes a dense matrix allows.
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# fp32 vector peak and HBM peak of MI355X (MI355X_MICROARCH.md, chip-level parameters)
-PEAK_FP32_VECTOR_TFLOPS = 157.3
+# MI355X_MICROARCH.md, chip-level parameters
+PEAK_F16_MFMA_TFLOPS = 2500.0      # dense bf16 / f16 matrix peak at 2.4 GHz
+PEAK_FP32_VECTOR_TFLOPS = 157.3    # 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz: packed fp32 only
+PEAK_FP64_VECTOR_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0
-PEAK_ISSUE_SLOTS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock
+# measured on MI355X boxes of this pool (profiles/r02_micro_*.txt), for context next to the data-sheet peaks
+SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS = 1570.0   # tools/mfma_stream.hip: 1.50-1.61 PFLOP/s on random f16 operands
+NONPACKED_FP32_FMA_TFLOPS = 147.4                # tools/valu_peak.hip: 7.37e13 v_fma_f32 lane-ops/s x 2
 
 KERNELS = {"gaussian": "gaussian", "absexp": "absolute-exponential", "invdist": "inverse-distance"}
-# per pair: flops counting fma = 2, transcendental = 1 (3D + 2E + 1 for gaussian, D=3, E=1)
-# and VALU issue slots counting a quarter-rate transcendental as 4
-FLOPS_PER_PAIR = {"gaussian": 12, "inverse-distance": 12, "absolute-exponential": 13}
-# VALU issue slots per pair of the pair-loop kernels: lowd_kernel (difference form: 6 for the
-# squared distance of the caller's coordinates + 1 multiply by log2 e where the kernel is an
-# exponential + transcendental(s) + 1 FMA) and fast_kernel (squared distance on the matrix cores:
-# only the transcendental(s) + 1 FMA stay on the VALU)
-SLOTS_PER_PAIR = {
-    "lowd_kernel": {"gaussian": 12, "inverse-distance": 11, "absolute-exponential": 16},
-    "fast_kernel": {"gaussian": 5, "inverse-distance": 5, "absolute-exponential": 9},
-    # centred form: + ~0.7 per pair for the operand rebuild and the reach flag
-    "cfast_kernel": {"gaussian": 5.7, "inverse-distance": 5.7, "absolute-exponential": 9.7},
-    # cell form: the exponential is range-reduced by grid cells and its remainder polynomial comes out of
-    # the matrix pipe; per pair the VALU owes ONE fma (the per-cell exponentials amortise to < 0.1 slot)
-    "cell_kernel": {"gaussian": 1.0},
+
+# Algorithmic work per pair of each pair-loop kernel, on the unit that bounds it.
+#   cellmm_kernel: one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs -> 2 x 16 = 32 matrix flop per pair
+#   cell_kernel:   the same MFMA (bf16) for the polynomial + ONE VALU fma per pair; the VALU is the busy unit
+#   fast / cfast:  squared distance on the matrix cores, transcendental + fma per pair on the VALU
+#   lowd_kernel:   SURVEY 8d's count, 3 D + 2 E + 1 = 12 flop per pair (fma = 2, exp = 1), all VALU
+#   mfma_*_kernel: 2 (D + E + 1) matrix flop per pair (QK^T-like distances + P [b | 1]), SURVEY 8d
+#   cell64_kernel: 11 fp64 fma-class instructions per pair = 22 flop
+ROOF = {
+    "cellmm_kernel": ("mfma", 32.0, PEAK_F16_MFMA_TFLOPS,
+                      "32 matrix flop per pair (one 32x32x16 f16 MFMA per 1024 pairs: polynomial remainder of the "
+                      "range-reduced exponential, weights and the sum over the sources in the accumulator) vs the dense "
+                      "f16 MFMA peak 2.5 PFLOP/s at 2.4 GHz"),
+    "cell_kernel": ("valu", 2.0, PEAK_FP32_VECTOR_TFLOPS,
+                    "2 VALU flop per pair (the one fma left after the bf16 MFMA delivers the polynomial) vs the "
+                    "packed-fp32 vector peak 157.3 TFLOP/s; v_fma_f32 (not packed) sustains 147 TFLOP/s here"),
+    "fast_kernel": ("valu", 12.0, PEAK_FP32_VECTOR_TFLOPS, "SURVEY 8d's 12 flop per pair vs the fp32 vector peak"),
+    "cfast_kernel": ("valu", 12.0, PEAK_FP32_VECTOR_TFLOPS, "SURVEY 8d's 12 flop per pair vs the fp32 vector peak"),
+    "lowd_kernel": ("valu", 12.0, PEAK_FP32_VECTOR_TFLOPS, "SURVEY 8d's 3D + 2E + 1 = 12 flop per pair vs the fp32 vector peak"),
+    "cell64_kernel": ("valu", 22.0, PEAK_FP64_VECTOR_TFLOPS,
+                      "11 fp64 fma-class instructions per pair (3 for t = 2 d.e, 7 Horner steps of exp(t), 1 accumulate) "
+                      "= 22 flop vs the fp64 vector peak 78.6 TFLOP/s"),
 }
-# VALU flops per pair the cell form needs by construction (one fma); its matrix-pipe flops per pair
-CELL_VALU_FLOPS_PER_PAIR = 2
-MFMA_FLOPS_PER_PAIR_CELL = 2 * 16  # one 32x32x16 bf16 MFMA per 1024 pairs
-MFMA_FLOPS_PER_PAIR_FAST = 2 * 32  # two 32x32x16 bf16 k-steps (K = 6 D + 6 = 24 -> 32) for D = 3
-PEAK_BF16_MFMA_TFLOPS = 2500.0
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--points", dest="n", type=float, default=1e6, help="points (N = M); default = BASELINE config 2")
-    p.add_argument("--kernel", choices=sorted(KERNELS), default="gaussian")
-    p.add_argument("--precision", choices=["float32", "float64"], default="float32")
-    p.add_argument("--sqdists", choices=["auto", "difference", "expanded", "cells"], default="auto",
-                   help="squared-distance form (the reference's fast_sqdists flag): auto = expanded form on "
-                        "the matrix cores where it is as accurate as the difference form")
+    p.add_argument("--steps", type=int, default=None, help="default: 10 (config 2, 3), 3 (4shard), 2 (4, 5)")
+    p.add_argument("--warmup", type=int, default=None, help="default: 2 (config 2, 3), 1 otherwise")
+    p.add_argument("--config", choices=["2", "3", "4", "4shard", "5"], default="2")
+    p.add_argument("--points", dest="n", type=float, default=None, help="override N = M of the config (not a BASELINE run)")
+    p.add_argument("--kernel", choices=sorted(KERNELS), default=None, help="config 2 only: another kernel function")
+    p.add_argument("--precision", choices=["float32", "float64"], default=None, help="config 2 only")
+    p.add_argument("--sqdists", choices=["auto", "difference", "expanded", "cells", "cells-valu"], default="auto",
+                   help="squared-distance form (the reference's fast_sqdists flag)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time budget of the row-sample baseline")
+    p.add_argument("--cpu-dense-sizes", default="10000", help="N = M of the dense numpy baseline (comma separated; "
+                                                               "SURVEY 8d asks for 10000,20000,30000)")
     p.add_argument("--all-ranks-on-device", type=int, default=None,
                    help="debug: put every rank on this one GPU (rehearses the multi-rank path on a 1-GPU box)")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the baseline sample")
     return p.parse_args()
 
 
-def cpu_baseline(kernel, y64, b64, precision, budget_s):
-    """oracle/ (C, OpenMP over target rows) on a bounded sample of target rows."""
+# ---------------------------------------------------------------------------------------------------------
+# CPU baselines (test infrastructure: oracle/)
+
+def cpu_port(kernel, y64, b64, precision, budget_s, normalize_rows=False, x64=None, shard=None):
+    """oracle/kmvp_oracle.c (C, OpenMP over target rows) on a bounded sample of target rows of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import c_oracle
 
-    n = y64.shape[0]
+    n = y64.shape[0] if x64 is None else x64.shape[0]
+    m = y64.shape[0]
     rs = np.random.RandomState(12345)
     threads = c_oracle.threads()
+    kw = dict(kernel=kernel, source_points=y64, source_signal=b64, precision=precision, normalize_rows=normalize_rows)
+    if x64 is not None:
+        kw["target_points"] = x64
+    if shard is not None:
+        kw.update(j_offset=shard[0], M_total=shard[1], raw_sums=True)
     probe = rs.choice(n, size=min(n, max(64, 2 * threads)), replace=False)
     t0 = time.time()
-    c_oracle.product(kernel=kernel, source_points=y64, source_signal=b64, rows=probe, precision=precision)
+    c_oracle.product(rows=probe, **kw)
     dt = max(time.time() - t0, 1e-4)
     rows = int(min(n, max(len(probe), len(probe) * budget_s / dt)))
     sample = rs.choice(n, size=rows, replace=False)
     t0 = time.time()
-    c_oracle.product(kernel=kernel, source_points=y64, source_signal=b64, rows=sample, precision=precision)
+    c_oracle.product(rows=sample, **kw)
     dt = time.time() - t0
     return {
-        "value": rows * float(n) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-        "sample": f"{rows} of {n} target rows x all {n} sources, {precision}, oracle/kmvp_oracle.c "
+        "value": rows * float(m) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+        "sample": f"{rows} of {n} target rows x all {m} sources, {precision}, oracle/kmvp_oracle.c "
                   f"(OpenMP, {threads} threads), {dt:.1f} s",
     }
 
+
+def cpu_dense(kernel, sizes, D=3):
+    """SURVEY 8d's CPU baseline: the numpy restatement of the reference's own algorithm -- fit() materialises the
+    N x M kernel matrix (bruteforce.py:113-120, slow (N,M,D) difference form or fast BLAS form), query() is K @ b
+    (:150-153) -- on the uniform_cube recipe, float64 and float32, both squared-distance forms.  pairs/s on
+    fit + query (what the harness' default axis shows) and on query alone (a GEMV over the stored matrix)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import kmvp_oracle
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = [f"{i.get('internal_api')} {i.get('version')} x{i.get('num_threads')}" for i in threadpool_info()
+                if i.get("user_api") == "blas"]
+    except Exception:
+        blas = []
+    rows = []
+    for n in sizes:
+        y, b = kmvp_oracle.uniform_cube(n, D)
+        for precision in ("float64", "float32"):
+            yp, bp = y.astype(precision), b.astype(precision)
+            for fast in (False, True):
+                if not fast and n > 20000 and precision == "float64":
+                    # the (N, M, D) buffer of the slow form: 8 N M D bytes = 21.6 GB at 3e4 -- still runs on this box
+                    pass
+                t0 = time.time()
+                K = kmvp_oracle.kernel_matrix(kernel=kernel, source_points=yp, fast_sqdists=fast)
+                fit = time.time() - t0
+                t0 = time.time()
+                a = K @ bp
+                query = time.time() - t0
+                del K
+                rows.append({"N": n, "precision": precision, "fast_sqdists": fast, "fit_s": round(fit, 4),
+                             "query_s": round(query, 5), "pairs_per_s_fit_plus_query": n * float(n) / (fit + query),
+                             "pairs_per_s_query_only": n * float(n) / max(query, 1e-9)})
+                del a
+    return {"kind": "port", "what": "oracle/kmvp_oracle.py kernel_matrix + K @ b (materialise K, then GEMV), "
+                                    "uniform_cube, D = 3, E = 1", "host_cores": os.cpu_count(), "blas": blas, "runs": rows}
+
+
+def head_commit(path):
+    """Short hash of the last commit that touched ``path`` (None outside a git checkout)."""
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "log", "-n1", "--format=%h", "--", path], capture_output=True, text=True,
+                             timeout=10)
+        return out.stdout.strip() or None
+    except Exception:
+        return None
+
+
+def traffic_from_profile(kname, tag):
+    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary of this kernel on this workload."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_{kname}_traffic.json")))
+    if not files:
+        return None, None
+    rel = os.path.relpath(files[-1], ROOT)
+    data = json.load(open(files[-1]))
+    return data.get("hbm_bytes_per_launch"), {"file": rel, "commit": head_commit(rel), "measured_in_this_run": False,
+                                              "note": "rocprofv3 --pmc passes of the same command on another lease; "
+                                                      "null when the kernel has no committed profile"}
+
+
+# ---------------------------------------------------------------------------------------------------------
 
 def main():
     args = parse()
@@ -107,23 +201,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = "WORLD_SIZE" in os.environ
-    if world != args.gpus and distributed:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # every rank checks the launch shape BEFORE anything touches a GPU, with a message that says what to change
+    if distributed and world != args.gpus:
+        raise SystemExit(f"[rank {rank}] --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if args.gpus > 1 and not distributed:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N")
+    if args.config in ("4shard", "5", "3") and args.gpus > 1:
+        raise SystemExit(f"--config {args.config} is a single-GPU measurement")
 
     import numpy as np
 
     # the host driver of this pool only supports dmabuf IPC (RCCL across processes needs it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    # Load the HIP library (system ROCm runtime) BEFORE torch, so that every GPU call of
-    # this process goes through one ROCm stack; torch is only used for the gloo
-    # rendezvous / barrier / max-over-ranks and never touches the GPU here.
+    # Load the HIP library (system ROCm runtime) BEFORE torch, so that every GPU call of this process goes
+    # through one ROCm stack; torch is only used for the gloo rendezvous / barrier / max-over-ranks.
     from kernel_matrix_benchmarks_amd import _lib, sharding
-    from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct
+    from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct, MI355XSolver
 
     _lib.load()
+    device = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
+    visible = _lib.device_count()  # hipGetDeviceCount only: no context is created
+    if visible < device + 1:
+        raise SystemExit(f"[rank {rank}] LOCAL_RANK={local_rank} needs GPU {device} but this process sees {visible} "
+                         f"device(s) (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}, "
+                         f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')})")
     dist = None
     comm = None
     if distributed:
@@ -138,43 +241,144 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    kernel = KERNELS[args.kernel]
-    n = int(args.n)
+    cfg = args.config
+    steps = args.steps if args.steps is not None else {"2": 10, "3": 10, "4shard": 3, "4": 2, "5": 2}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"2": 2, "3": 2}.get(cfg, 1)
+
+    # ---- the workload -------------------------------------------------------------------------------------
     D, E = 3, 1
+    normalize = False
+    solver = False
+    shard = None
+    if cfg == "2":
+        kernel = KERNELS[args.kernel or "gaussian"]
+        precision = args.precision or "float32"
+        n = int(args.n or 1e6)
+    elif cfg == "3":
+        kernel, precision, normalize = "absolute-exponential", "bfloat16", True
+        n, D, E = int(args.n or 65536), 64, 64
+    elif cfg in ("4", "4shard"):
+        kernel, precision = "inverse-distance", "float32"
+        n = int(args.n or 1e7)
+    else:
+        kernel, precision, solver = "gaussian", "float64", True
+        n = int(args.n or 1e5)
     rs = np.random.RandomState(n + D)  # datasets.py:258
     y = rs.rand(n, D)
+    if cfg == "3":
+        y = y / np.sqrt(D)  # otherwise |x - y| ~ 3.3 and every weight is ~ e^-3.3
     b = rs.randn(n, E)
+    pairs = float(n) * float(n)
 
-    fast = {"auto": None, "difference": False, "expanded": True, "cells": "cells"}[args.sqdists]
-    device = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
-    algo = MI355XProduct(kernel=kernel, dimension=D, precision=args.precision, device=device, comm=comm,
-                         fast_sqdists=fast)
-    algo.prepare_data(source_points=y, target_points=y, same_points=True)  # H2D, untimed (runner.py:75-80)
-    algo.fit()  # cell order and tile lists (timed by the harness as build_time, not part of a step)
-    algo.prepare_query(source_signal=b)
-    for _ in range(args.warmup):
-        algo.query()
+    fast = {"auto": None, "difference": False, "expanded": True, "cells": "cells", "cells-valu": "cells-valu"}[args.sqdists]
+    extra = {}
+    if cfg == "4shard":
+        # one of eight ranks' share, no communicator: the library is told so explicitly (partial_shard)
+        r8, w8 = 3, 8
+        lo, hi = n * r8 // w8, n * (r8 + 1) // w8
+        shard = (lo, hi)
+        ctx = _lib.Context(device)
+        ctx.set_option("same_points_global", 1)
+        ctx.set_option("partial_shard", 1)
+        y32 = y.astype(np.float32)
+        ctx.set_points(np.ascontiguousarray(y32[lo:hi]), y32, _lib.KMVP_F32, j_offset=lo, M_total=n)
+        ctx.set_signal(np.ascontiguousarray(b[lo:hi], dtype=np.float32))
+        pairs = float(n) * float(hi - lo)
 
-    kernel_ms = []
-    barrier()  # query() is synchronous on the device, so the GPU is idle here
+        def step():
+            ctx.run(kernel, False)
+            return ctx.last_kernel_ms, ctx.last_total_ms
+
+        def result():
+            return ctx.get_result(n, 1)
+
+        def info():
+            return {"device_kernel": ctx.last_kernel_name, "rccl_ranks": 1, "allreduce_ms": 0.0,
+                    "device_bytes": ctx.device_bytes}
+
+        done = ctx.close
+    elif solver:
+        prod = MI355XProduct(kernel=kernel, dimension=D, precision=np.float64, device=device)
+        prod.prepare_data(source_points=y, target_points=y, same_points=True)
+        prod.fit()
+        prod.prepare_query(source_signal=b)
+        prod.query()
+        a_rhs = prod.get_result()  # a := K b from the float64 product
+        prod.query()               # (the first query also packs the layouts)
+        operator_ms = prod.device_kernel_ms
+        operator_kernel = prod.device_kernel
+        prod.done()
+        algo = MI355XSolver(kernel=kernel, dimension=D, precision=np.float64, device=device, rtol=1e-6, maxit=5000)
+        algo.prepare_data(source_points=y)
+        algo.fit()
+        algo.prepare_query(target_signal=a_rhs)
+
+        def step():
+            algo.query()
+            return operator_ms, 0.0
+
+        def result():
+            return algo.get_result()
+
+        def info():
+            d = algo.get_additional()
+            d["device_kernel"] = operator_kernel
+            d["allreduce_ms"] = 0.0
+            return d
+
+        done = algo.done
+    else:
+        algo = MI355XProduct(kernel=kernel, dimension=D, normalize_rows=normalize, precision=precision, device=device,
+                             comm=comm, fast_sqdists=fast)
+        algo.prepare_data(source_points=y, target_points=y, same_points=True)  # H2D, untimed (runner.py:75-80)
+        algo.fit()  # cell order and tile lists (the harness books it as build_time; not part of a step)
+        algo.prepare_query(source_signal=b)
+
+        def step():
+            algo.query()  # pair loop + segment reduction + [RCCL all-reduce] + finish, then stream sync
+            return algo.device_kernel_ms, algo.device_total_ms
+
+        def result():
+            return algo.get_result()
+
+        def info():
+            return algo.get_additional()
+
+        done = algo.done
+
+    for _ in range(warmup):
+        step()
+    kernel_ms, total_ms, allreduce_ms = [], [], []
+    barrier()  # every step is synchronous on the device, so the GPU is idle here
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        algo.query()  # pair loop + segment reduction + [RCCL all-reduce] + finish, then stream sync
-        kernel_ms.append(algo.device_kernel_ms)
+    for _ in range(steps):
+        k_ms, t_ms = step()
+        kernel_ms.append(k_ms)
+        total_ms.append(t_ms)
+        if not solver and cfg != "4shard":
+            allreduce_ms.append(algo._ctx.last_allreduce_ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    total_ms = algo.device_total_ms
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
-    a = algo.get_result()
-    kname = algo.device_kernel
-    # the other squared-distance form on the same resident data, for the record (3 steps, untimed region)
-    other = None
-    expanded = None
-    if args.sqdists == "auto" and kname in ("fast_kernel", "cfast_kernel", "cell_kernel") and world == 1:
+    a = result()
+    meta = info()
+    kname = meta["device_kernel"]
+    rccl_ranks = int(meta.get("rccl_ranks", 1))
+    if dist is not None:
+        # every rank's RCCL communicator must span all ranks: a line with n_gpus = N and rccl_ranks < N is void
+        seen = torch.tensor([rccl_ranks], dtype=torch.int64)
+        dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+        rccl_ranks = int(seen[0])
+        if rccl_ranks != world:
+            raise SystemExit(f"[rank {rank}] RCCL communicator spans {rccl_ranks} rank(s), expected {world}")
+
+    # the other forms on the same resident data, for the record (config 2, one GPU, untimed region)
+    others = {}
+    if cfg == "2" and args.sqdists == "auto" and world == 1 and kname in ("cellmm_kernel", "cell_kernel", "fast_kernel"):
         def side_run(code):
             algo.set_query_arguments(fast_sqdists=code)
             algo.query()
@@ -183,107 +387,165 @@ def main():
                 algo.query()
                 oms.append(algo.device_kernel_ms)
             return {"kernel": algo.device_kernel, "kernel_ms": float(np.mean(oms)),
-                    "pairs_per_s": float(n) * float(n) / (float(np.mean(oms)) * 1e-3)}
+                    "pairs_per_s": pairs / (float(np.mean(oms)) * 1e-3)}
 
-        other = side_run(0)
-        if kname == "cell_kernel":
-            expanded = side_run(1)  # fast_kernel: one v_exp_f32 per pair, squared distance on the matrix cores
+        others["difference_form"] = side_run(0)
+        others["expanded_form"] = side_run(1)
+        if kname == "cellmm_kernel":
+            others["cell_form_valu_sum"] = side_run(4)
         algo.set_query_arguments(fast_sqdists=-1)
-    max_err = rel_err = None
+
     if rank == 0:
-        # max |err| against the float64 oracle on a fixed sample of rows (BASELINE metric's error leg)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import c_oracle
 
+        # ---- error leg of the metric: against the float64 C restatement of the reference on sampled rows
         rows = np.random.RandomState(0).choice(n, size=min(n, 256), replace=False)
-        truth = c_oracle.product(kernel=kernel, source_points=y, source_signal=b, rows=rows)
-        max_err = float(np.max(np.abs(a[rows] - truth)))
-        rel_err = max_err / float(np.max(np.abs(truth)))
+        err = {}
+        if solver:
+            Kb = c_oracle.product(kernel=kernel, source_points=y, source_signal=a, rows=rows)
+            err = {"residual_rows": float(np.linalg.norm(Kb - a_rhs[rows]) / np.linalg.norm(a_rhs[rows])),
+                   "residual_reported": float(meta["cg_relative_residual"]), "iterations": int(meta["cg_iterations"]),
+                   "converged": bool(meta["cg_converged"])}
+            max_err = rel_err = None
+            products = meta["cg_iterations"] + 1  # + the true-residual product
+            pairs_per_step = pairs * products
+        else:
+            if shard is not None:
+                truth, _ = c_oracle.product(kernel=kernel, source_points=y[shard[0]:shard[1]], target_points=y,
+                                            source_signal=b[shard[0]:shard[1]], rows=rows, j_offset=shard[0], M_total=n,
+                                            raw_sums=True)
+            else:
+                truth = c_oracle.product(kernel=kernel, source_points=y, source_signal=b, rows=rows,
+                                         normalize_rows=normalize)
+            norms = np.sqrt(np.sum((a[rows] - truth) ** 2, axis=-1))  # plotting/metrics.py:53-56
+            max_err = float(np.max(norms))
+            rel_err = max_err / float(np.max(np.sqrt(np.sum(truth ** 2, axis=-1))))
+            pairs_per_step = pairs
 
-    if rank == 0:
-        pairs = float(n) * float(n)
-        sec_per_step = elapsed / args.steps
+        sec_per_step = elapsed / steps
         k_ms = float(np.mean(kernel_ms))
-        shard_pairs = float(n) * float(algo.shard[1] - algo.shard[0])
-        # roofline.achieved counts the flops the bounding unit (VALU) has to execute for this algorithm:
-        # SURVEY 8d's 3D + 2E + 1 = 12 per pair for the kernels that evaluate exp() per pair on the VALU;
-        # the cell form leaves one fma (2 flops) per pair there -- the rest runs on the matrix pipe, so
-        # the 12-flop count is reported beside it as an equivalent, not as a fraction of the vector peak
-        flops_per_pair = CELL_VALU_FLOPS_PER_PAIR if kname == "cell_kernel" else FLOPS_PER_PAIR[kernel]
-        flops = flops_per_pair * shard_pairs
-        achieved_tflops = flops / (k_ms * 1e-3) / 1e12
-        traffic = None
-        # HBM-side bytes per launch of this exact workload, measured with rocprofv3 PMC passes
-        # (tools/profile_bench.sh -> tools/summarize_profile.py); latest committed round wins
-        import glob
-
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_gaussian_1e6_f32_{kname}_traffic.json")))
-        if tfiles and world == 1 and n == 1000000 and kernel == "gaussian" and args.precision == "float32":
-            traffic = json.load(open(tfiles[-1])).get("hbm_bytes_per_launch")
-        tiles = -(-n // 64)  # one 64-lane wavefront per target tile (T = 1)
+        my_sources = n if shard is not None or solver else (algo.shard[1] - algo.shard[0])
+        if shard is not None:
+            my_sources = shard[1] - shard[0]
+        shard_pairs = float(n) * float(my_sources)
+        if kname in ("mfma_pipe_kernel", "mfma_kernel"):
+            bound, fpp, peak, basis = ("mfma", 2.0 * (D + E + 1), PEAK_F16_MFMA_TFLOPS,
+                                       "2 (D + E + 1) matrix flop per pair (distances + P [b | 1], SURVEY 8d) vs the dense "
+                                       "bf16 MFMA peak; the transcendental rate bounds it equally (one sqrt + one exp2 per pair)")
+        else:
+            bound, fpp, peak, basis = ROOF.get(kname, ROOF["lowd_kernel"])
+        achieved = fpp * shard_pairs / (k_ms * 1e-3) / 1e12
+        tag = {"2": f"{'gaussian' if kernel == 'gaussian' else args.kernel}_1e6_{'f32' if precision == 'float32' else 'f64'}",
+               "3": "c3_absexp_bf16", "4": "c4_invdist_1e7_f32", "4shard": "c4shard_invdist_f32", "5": "c5_gaussian_1e5_f64"}[cfg]
+        traffic, traffic_source = (traffic_from_profile(kname, tag) if n == {"2": 1000000, "3": 65536, "4": 10000000,
+                                                                             "4shard": 10000000, "5": 100000}[cfg]
+                                   and world == 1 else (None, None))
+        esize = 8 if precision == "float64" else (2 if precision == "bfloat16" else 4)
         out = {
             "metric": "point-pair interactions/s (N*M/s) + max |err| vs scipy, D=3 Gaussian",
-            "value": pairs / sec_per_step,
+            "value": pairs_per_step / sec_per_step,
             "unit": "pairs/s",
             "n_gpus": args.gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "float32" else "f64",
+            "dtype": {"float32": "f32", "float64": "f64", "bfloat16": "bf16"}[precision],
             "data": "synthetic",
             "config": {
-                "workload": f"{kernel} product, uniform-3D (uniform_cube seed n+D), N=M={n}, D=3, E=1, "
-                            f"{args.precision}, same_points",
-                "sharding": f"sources split over {args.gpus} GPU(s), one RCCL all-reduce of (N,E) f64 per step"
-                            if args.gpus > 1 else "single GPU",
+                "workload": {
+                    "2": f"BASELINE config 2: {kernel} product, uniform-3D (uniform_cube seed n+D), N=M={n}, D=3, E=1, "
+                         f"{precision}, same_points",
+                    "3": f"BASELINE config 3: exp(-r) attention (row-normalised), uniform points / sqrt(D), N=M={n}, D={D}, "
+                         f"E={E}, bf16 MFMA tiles, same_points",
+                    "4": f"BASELINE config 4: inverse-distance product, uniform-3D, N=M={n}, D=3, E=1, float32, sources "
+                         f"sharded over {args.gpus} GPU(s)",
+                    "4shard": f"BASELINE config 4, one of 8 source shards on one GPU: {n} targets x {my_sources} sources "
+                              f"(rank 3 of 8, global zero rule), inverse-distance, float32",
+                    "5": f"BASELINE config 5: Gaussian solver K b = a, uniform-3D, N=M={n}, D=3, float64, CG on the HIP "
+                         f"matvec, rtol 1e-6; one step = one solve ({err.get('iterations')} iterations + 1 residual product)",
+                }[cfg],
+                "sharding": (f"sources split over {args.gpus} GPUs, one RCCL all-reduce of the (N,E) f64 sums per step"
+                             if args.gpus > 1 else "single GPU"),
+                "kernel_form": {
+                    "cellmm_kernel": "cells: exp() range-reduced by grid cells; polynomial remainder, source weights and the "
+                                     "sum over the sources in ONE 32x32x16 f16 MFMA per 1024 pairs (fp32 accumulator carried "
+                                     "over a source cell)",
+                    "cell_kernel": "cells: exp() range-reduced by grid cells, remainder polynomial from one bf16 MFMA per "
+                                   "1024 pairs, one VALU fma per pair",
+                    "fast_kernel": "expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "
+                                   "(reference fast_sqdists=True form)",
+                    "cfast_kernel": "expanded around per-group centres of Morton-sorted sources on the bf16 matrix cores, "
+                                    "closest pairs recomputed exactly",
+                    "cell64_kernel": "float64 cells: exp() range-reduced by grid cells, degree-7 remainder on the fp64 VALU",
+                }.get(kname, "difference form (reference fast_sqdists=False)" if "lowd" in kname else kname),
             },
+            "rccl_ranks": rccl_ranks,
             "max_abs_err": max_err,
             "max_rel_err": rel_err,
+            "error_reference": "float64 oracle/kmvp_oracle.c (C restatement of the reference's scipy/numpy bruteforce, pinned "
+                               "by tests/golden), 256 sampled rows; all rows: tests/test_gpu_parity.py::test_config2_*",
             "roofline": {
-                "bound": "valu",
+                "bound": bound,
                 "kernel": kname,
-                "achieved": achieved_tflops,
-                "peak": PEAK_FP32_VECTOR_TFLOPS,
+                "achieved": achieved,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_VECTOR_TFLOPS,
+                "frac": achieved / peak,
+                "frac_basis": basis,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel_ms": k_ms,
-                "step_device_ms": total_ms,
-                "flops_per_pair": flops_per_pair,
-                "survey_equivalent_tflops": FLOPS_PER_PAIR[kernel] * shard_pairs / (k_ms * 1e-3) / 1e12,
-                # the same launch priced in VALU issue slots (transcendental = 4 slots)
-                "issue_slots_per_pair": SLOTS_PER_PAIR.get(kname, SLOTS_PER_PAIR["lowd_kernel"])[kernel],
-                "issue_frac": SLOTS_PER_PAIR.get(kname, SLOTS_PER_PAIR["lowd_kernel"])[kernel] * shard_pairs
-                              / (k_ms * 1e-3) / PEAK_ISSUE_SLOTS,
-                "mfma_frac": ((MFMA_FLOPS_PER_PAIR_CELL if kname == "cell_kernel" else MFMA_FLOPS_PER_PAIR_FAST)
-                              * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
-                              if kname in ("fast_kernel", "cfast_kernel", "cell_kernel") else 0.0),
-                # north-star's "HBM" reading: bytes every wavefront streams from the source block
-                "source_stream_GBps": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4 / (k_ms * 1e-3) / 1e9,
-                "source_stream_frac_of_hbm_peak": tiles * float(algo.shard[1] - algo.shard[0]) * (D + E) * 4
-                                                  / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                "algorithmic_hbm_bytes": 4 * (n * D + (algo.shard[1] - algo.shard[0]) * (D + E) + n * E),
+                "step_device_ms": float(np.mean(total_ms)) if not solver else None,
+                "allreduce_ms": float(np.mean(allreduce_ms)) if allreduce_ms else 0.0,
+                "flops_per_pair": fpp,
+                "algorithmic_hbm_bytes": esize * (n * D + my_sources * (D + E) + n * E),
             },
         }
-        out["config"]["sqdists"] = ("cells: exp() range-reduced by grid cells, remainder polynomial of 2 d.e on the bf16 "
-                                    "matrix cores (one 32x32x16 MFMA per 1024 pairs), one fma per pair on the VALU"
-                                    if kname == "cell_kernel" else
-                                    "expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "
-                                    "(reference fast_sqdists=True form)" if kname == "fast_kernel"
-                                    else "expanded around per-group centres of Morton-sorted sources on the bf16 matrix "
-                                         "cores, closest pairs recomputed exactly" if kname == "cfast_kernel"
-                                    else "difference form (reference fast_sqdists=False)")
-        if other is not None:
-            out["difference_form"] = other
-        if expanded is not None:
-            out["expanded_form"] = expanded
+        r = out["roofline"]
+        if bound == "mfma" and kname == "cellmm_kernel":
+            r["sustained_peak_random_data"] = SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS
+            r["frac_of_sustained"] = achieved / SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS
+            r["sustained_note"] = ("tools/mfma_stream.hip on this pool: the same MFMA sustains 2.48 PFLOP/s on zero operands "
+                                   "but 1.50-1.61 PFLOP/s on random f16 operands (power limit, clock ~2.0 GHz): "
+                                   "profiles/r02_micro_mfma_stream.txt")
+        if kname in ("cellmm_kernel", "cell_kernel", "fast_kernel", "cfast_kernel") and cfg in ("2", "4", "4shard"):
+            # SURVEY 8d's VALU model (12 flop per pair against the fp32 vector peak) does not describe kernels whose
+            # exponential / squared distance runs on the matrix pipe; reported as an equivalent only
+            r["survey_equivalent_tflops"] = 12.0 * shard_pairs / (k_ms * 1e-3) / 1e12
+            r["survey_equivalent_note"] = ("SURVEY 8d prices a pair at 12 VALU flop; this kernel moved that work to the matrix "
+                                           "pipe, so the figure may exceed the 157.3 TFLOP/s vector peak: it is an "
+                                           "equivalent, not a fraction of any unit's peak")
+        if kname == "cell_kernel":
+            r["nonpacked_fp32_ceiling_tflops"] = NONPACKED_FP32_FMA_TFLOPS
+            r["mfma_frac"] = 32.0 * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
+        if cfg in ("2", "4", "4shard"):
+            tiles = -(-n // 64)  # the north star's reading: every 64-target wavefront streams the whole source block
+            r["source_stream_GBps"] = tiles * float(my_sources) * (D + E) * 4 / (k_ms * 1e-3) / 1e9
+            r["source_stream_frac_of_hbm_peak"] = r["source_stream_GBps"] / PEAK_HBM_GBPS
+        if solver:
+            out["solver"] = err
+            out["config"]["operator_ms"] = operator_ms
+        out.update(others)
         if not args.no_cpu_baseline and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(kernel, y, b, args.precision, args.cpu_seconds)
+            if shard is not None:
+                base = cpu_port(kernel, y[shard[0]:shard[1]], b[shard[0]:shard[1]], "float32", args.cpu_seconds, x64=y,
+                                shard=(shard[0], n))
+            else:
+                base = cpu_port(kernel, y, b, "float32" if precision == "bfloat16" else precision, args.cpu_seconds,
+                                normalize_rows=normalize)
+            if solver:
+                base["sample"] += " -- ONE operator application; the reference's dense lstsq (bruteforce.py:193-207) needs " \
+                                  "80 GB and O(M^3) = 1e15 flop at this size and cannot run"
+            sizes = [int(float(s)) for s in args.cpu_dense_sizes.split(",") if s]
+            if sizes and cfg == "2":
+                base["dense"] = cpu_dense(kernel, sizes)
+            out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
-    algo.done()
+    done()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
