@@ -33,10 +33,11 @@ __global__ void __launch_bounds__(CELL_TILE) pack_cellmm_points_kernel(
 }
 
 // max |b| as the bits of a non-negative float (they order like unsigned integers; a NaN wins)
-__global__ void cellmm_absmax_kernel(const float* __restrict__ b, int64_t n, unsigned* __restrict__ out) {
+// (column `col` of the row-major (n, E) signal)
+__global__ void cellmm_absmax_kernel(const float* __restrict__ b, int64_t n, int E, int col, unsigned* __restrict__ out) {
   unsigned m = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const unsigned v = (unsigned)__float_as_int(b[i]) & 0x7fffffffu;
+    const unsigned v = (unsigned)__float_as_int(b[i * E + col]) & 0x7fffffffu;
     m = v > m ? v : m;
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -63,17 +64,18 @@ __global__ void cellmm_scale_kernel(const unsigned* __restrict__ bmax_bits, int 
   scale[1] = ldexpf(1.f, -ex - 6);
 }
 
-// one block of 32 threads per source tile: the signal part of the stage image, b sigma_b (0 for pad sources);
-// b == nullptr: density estimation (b = 1)
+// one block of 32 threads per source tile: the signal part of the stage image, b sigma_b (0 for pad sources), for
+// column `col` of the row-major (M, E) signal; b == nullptr: b = 1 (density estimation, the denominator of
+// normalised rows)
 __global__ void __launch_bounds__(CELL_TILE) pack_cellmm_signal_kernel(
-    const float* __restrict__ b, const int* __restrict__ perm, const int* __restrict__ gstart,
+    const float* __restrict__ b, int E, int col, const int* __restrict__ perm, const int* __restrict__ gstart,
     const int* __restrict__ gcnt, int64_t n_groups, const float* __restrict__ scale, unsigned char* __restrict__ img) {
   const int64_t g = blockIdx.x;
   const int r = threadIdx.x;
   unsigned char* stage = img + (g / CMM_STAGE_TILES) * CMM_STAGE_BYTES;
   const int q = (int)(g % CMM_STAGE_TILES);
   const bool valid = g < n_groups && r < gcnt[g];
-  const float bj = valid ? (b ? b[perm[gstart[g] + r]] : 1.f) : 0.f;
+  const float bj = valid ? (b ? b[(int64_t)perm[gstart[g] + r] * E + col] : 1.f) : 0.f;
   *reinterpret_cast<float*>(stage + CMM_B_OFF + (q * CELL_TILE + r) * 4) = bj * scale[0];
 }
 

@@ -913,9 +913,13 @@ int cellmm_wlog2(const kmvp_ctx* c) {
   return (int)std::ceil(arg * 1.4426950408889634);
 }
 
+// One launch per signal column (and one with b = 1 for the denominator of normalised rows): the weights W_j b_j
+// live in the MFMA's source operand, so a column is an operand, not an extra fma.  E columns cost E launches of
+// ~27 us per 1e9 pairs each -- against 3.5 E VALU slots per pair for the column-blocked difference form.
 int run_product_cellmm(kmvp_ctx* c, int sig) {
   const int D = c->D;
-  const int E = 1;
+  const int E = sig == SIG_DENSITY ? 1 : c->E;
+  const int NE = sig == SIG_NORM ? E + 1 : E;
   const int64_t N = c->N;
   const bool small = N < SMALL_PROBLEM_TARGETS;
   const int TT = c->cell_tt;  // the target tile list was built for it (cell_prepare)
@@ -933,7 +937,8 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
 
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
                          c->packed_layout != LAYOUT_CELLMM || c->packed_T != TT;
-  const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  // the image holds ONE column's signal: it can be reused only by single-column products
+  const bool sig_stale = pts_stale || NE > 1 || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   const int* tperm = (const int*)(c->same_points ? c->cell_sperm.p : c->cell_tperm.p);
   const int* tgrp = (const int*)c->cell_tgrp.p;
@@ -941,6 +946,7 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   if ((rc = ensure(c, c->cell_scale, 64))) return rc;
   float* scale = (float*)c->cell_scale.p;
   unsigned* bmax = (unsigned*)c->cell_scale.p + 4;
+  HIP_TRY(c, mark(c, 0));
   if (pts_stale) {
     if ((rc = ensure(c, c->xs, (size_t)n_slots * 4 * sizeof(float)))) return rc;
     if ((rc = ensure(c, c->cell_tmeta, (size_t)n_tiles * 4 * sizeof(float)))) return rc;
@@ -952,28 +958,18 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
     hipLaunchKernelGGL(pack_cellmm_points_kernel, dim3((unsigned)(m_stages * CMM_STAGE_TILES)), dim3(CELL_TILE), 0,
                        c->stream, (const float*)c->y_raw.p, (const int*)c->cell_sperm.p, sgrp, sgrp + c->cell_m_tiles,
                        (const unsigned*)(sgrp + 2 * c->cell_m_tiles), c->cell_m_tiles, D, grid, (unsigned char*)c->rec.p);
+    HIP_TRY(c, hipGetLastError());
   }
-  if (sig_stale) {  // only the signal part of the image: max |b| -> sigma_b -> b sigma_b in tile order
-    const float* b = sig == SIG_DENSITY ? (const float*)nullptr : (const float*)c->b_raw.p;
-    HIP_TRY(c, hipMemsetAsync(bmax, 0, sizeof(unsigned), c->stream));
-    if (b)
-      hipLaunchKernelGGL(cellmm_absmax_kernel, dim3((unsigned)std::min<int64_t>(1024, (c->M + 255) / 256)), dim3(256), 0,
-                         c->stream, b, c->M, bmax);
-    hipLaunchKernelGGL(cellmm_scale_kernel, dim3(1), dim3(1), 0, c->stream, (const unsigned*)bmax, cellmm_wlog2(c),
-                       b ? 0 : 1, scale);
-    hipLaunchKernelGGL(pack_cellmm_signal_kernel, dim3((unsigned)(m_stages * CMM_STAGE_TILES)), dim3(CELL_TILE), 0,
-                       c->stream, b, (const int*)c->cell_sperm.p, sgrp, sgrp + c->cell_m_tiles, c->cell_m_tiles,
-                       (const float*)scale, (unsigned char*)c->rec.p);
-  }
-  HIP_TRY(c, hipGetLastError());
   c->packed_points_ver = c->points_ver;
   c->packed_signal_ver = c->signal_ver;
   c->packed_kernel = K_GAUSSIAN;
-  c->packed_sig = sig;
+  c->packed_sig = NE > 1 ? -1 : sig;
   c->packed_layout = LAYOUT_CELLMM;
   c->packed_T = TT;
 
   if ((rc = ensure(c, c->part, (size_t)segments * n_slots * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->sums, (size_t)NE * N * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->cell_sums, (size_t)NE * n_slots * sizeof(double)))) return rc;
   CellmmArgs a;
   a.xd = (const float*)c->xs.p;
   a.tmeta = (const float*)c->cell_tmeta.p;
@@ -986,21 +982,38 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   a.segments = segments;
   a.tile_blocks = (int)tile_blocks;
   const dim3 grid_dim((unsigned)(tile_blocks * segments));
-  HIP_TRY(c, mark(c, 0));
-  hipError_t le = launch_cellmm_gaussian(TT, a, grid_dim, c->stream, &c->last_kernel_name);
-  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2, 4 or 8");
-  HIP_TRY(c, le);
-  HIP_TRY(c, mark(c, 1));
+  if (NE == 1 && !sig_stale) HIP_TRY(c, mark(c, 0));  // resident signal: the timed region is the pair loop alone
+  for (int col = 0; col < NE; ++col) {
+    if (sig_stale) {  // the signal part of the image: max |b| -> sigma_b -> b sigma_b in tile order
+      const float* b = (sig == SIG_DENSITY || col == E) ? (const float*)nullptr : (const float*)c->b_raw.p;
+      HIP_TRY(c, hipMemsetAsync(bmax, 0, sizeof(unsigned), c->stream));
+      if (b)
+        hipLaunchKernelGGL(cellmm_absmax_kernel, dim3((unsigned)std::min<int64_t>(1024, (c->M + 255) / 256)), dim3(256), 0,
+                           c->stream, b, c->M, E, col, bmax);
+      hipLaunchKernelGGL(cellmm_scale_kernel, dim3(1), dim3(1), 0, c->stream, (const unsigned*)bmax, cellmm_wlog2(c),
+                         b ? 0 : 1, scale);
+      hipLaunchKernelGGL(pack_cellmm_signal_kernel, dim3((unsigned)(m_stages * CMM_STAGE_TILES)), dim3(CELL_TILE), 0,
+                         c->stream, b, E, col, (const int*)c->cell_sperm.p, sgrp, sgrp + c->cell_m_tiles, c->cell_m_tiles,
+                         (const float*)scale, (unsigned char*)c->rec.p);
+      HIP_TRY(c, hipGetLastError());
+      if (NE == 1) HIP_TRY(c, mark(c, 0));
+    }
+    hipError_t le = launch_cellmm_gaussian(TT, a, grid_dim, c->stream, &c->last_kernel_name);
+    if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2, 4 or 8");
+    HIP_TRY(c, le);
+    if (NE == 1) HIP_TRY(c, mark(c, 1));
+    // segments -> this column's sums in cell order
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(n_slots)), dim3(256), 0, c->stream,
+                       (const double*)c->part.p, (double*)c->cell_sums.p + (size_t)col * n_slots, n_slots, segments);
+    HIP_TRY(c, hipGetLastError());
+  }
+  if (NE > 1) HIP_TRY(c, mark(c, 1));  // several columns: the "kernel" time covers every column's pack + pair loop
 
-  // ---- epilogue: segments -> sums in the caller's order, [all-reduce over the source shards]
-  if ((rc = ensure(c, c->sums, (size_t)N * sizeof(double)))) return rc;
-  if ((rc = ensure(c, c->cell_sums, (size_t)n_slots * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(n_slots)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->cell_sums.p, n_slots, segments);
-  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for(N)), dim3(256), 0, c->stream,
-                     (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, 1);
+  // ---- epilogue: back to the caller's order, [all-reduce over the source shards], normalise
+  hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream,
+                     (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, NE);
   HIP_TRY(c, hipGetLastError());
-  return finish_product(c, N, N, N, E, sig);
+  return finish_product(c, (int64_t)NE * N, N, N, E, sig);
 }
 
 // ---- float64 cell path (kmvp_cell64.hpp): Gaussian, D <= 3, E == 1, plain product ----------------------
@@ -1319,6 +1332,21 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   }
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
+  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->density && c->E > 1 && !c->async_product &&
+      c->centre_ver == c->points_ver && (c->opt_fast == 3 || c->opt_fast < 0)) {
+    // several signal columns (low-D attention with E value channels): one cellmm_kernel launch per column where the
+    // cell form applies (same rule as for E = 1 below)
+    const float sc = scale_for<float>(kernel);
+    const bool global_ok = c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
+    if (global_ok && (c->opt_fast == 3 || (c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
+      const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : 0);
+      int rc = cell_prepare(c, TT);
+      if (rc) return rc;
+      if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD) &&
+          cellmm_wlog2(c) <= CMM_MAX_WLOG2)
+        return run_product_cellmm(c, sig);
+    }
+  }
   if (c->dtype == KMVP_F32 && c->D <= FAST_MAX_D && (c->density || c->E == 1) && c->centre_ver == c->points_ver) {
     // "fast_sqdists": squared distances in the expanded form on the matrix cores.
     //   fast_kernel  one centre for the whole cloud: absolute error eps32 (|x'|^2 + |y'|^2) in s
@@ -1342,10 +1370,9 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       if (rc) return rc;
       if (c->cell_state == 1 && (c->opt_fast >= 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) {
         // cellmm_kernel (weights in the operand, sum in the accumulator) where its f16 operands have the range:
-        // plain products and densities on clouds inside the radius rule; cell_kernel otherwise (normalised
-        // rows, wide clouds) or on request (fast_sqdists = 4)
-        if (c->opt_fast != 4 && sig != SIG_NORM && global_ok && cellmm_wlog2(c) <= CMM_MAX_WLOG2)
-          return run_product_cellmm(c, sig);
+        // clouds inside the radius rule; cell_kernel otherwise (wide clouds) or on request (fast_sqdists = 4)
+        if (c->opt_fast != 4 && global_ok && cellmm_wlog2(c) <= CMM_MAX_WLOG2)
+          return run_product_cellmm(c, sig);  // normalised rows: a second launch with b = 1 for the denominator
         return run_product_cell(c, sig);
       }
     }
