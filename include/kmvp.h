@@ -154,11 +154,15 @@ int kmvp_comm_rank(const kmvp_ctx* ctx);
  *                      1 = always, around one centre for the whole cloud (fast_kernel);
  *                      2 = always, around per-group centres of Morton-sorted sources with exact
  *                          recomputation of the closest pairs (cfast_kernel, D <= 4);
- *                      3 = always the cell form (cell_kernel: Gaussian, D <= 3): exp() is range-reduced
- *                          by the cells of a regular grid, exp(-|x-y|^2) = U_i(S) W_j(T) exp(2 d.e),
- *                          and the remainder polynomial 1 + t + t^2/2 of t = 2 d.e (|t| <= 0.016)
- *                          comes out of one bf16 MFMA per 32 x 32 pairs; float64 (cell64_kernel,
- *                          E == 1): the degree-7 polynomial on the VALU;
+ *                      3 = always the cell form (Gaussian, D <= 3): exp() is range-reduced by the cells
+ *                          of a regular grid, exp(-|x-y|^2) = U_i(S) W_j(T) exp(2 d.e), and the remainder
+ *                          polynomial 1 + t + t^2/2 of t = 2 d.e (|t| <= 0.016) comes out of one MFMA per
+ *                          32 x 32 pairs -- cellmm_kernel: f16 MFMA that also carries the weights W_j b_j
+ *                          and the sum over the sources (any E: one launch per signal column; normalised
+ *                          rows: one more with b = 1), on clouds inside the radius rule; cell_kernel
+ *                          (bf16 MFMA for the polynomial, one VALU fma per pair; E == 1) otherwise;
+ *                          float64 (cell64_kernel, E == 1): the degree-7 polynomial on the VALU;
+ *                      4 = as 3 but always cell_kernel (float32);
  *                      0 = never (difference form, bruteforce.py:53-54);
  *                      -1 = auto (default): the cheapest form that is as accurate as the
  *                          difference form -- for the Gaussian on clouds of small scaled radius
@@ -171,7 +175,7 @@ int kmvp_comm_rank(const kmvp_ctx* ctx);
  *                      a call fails with KMVP_E_INVALID instead of passing partial sums off as the product
  *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4, 8
  *                      (clamped to what is instantiated: fast_kernel 4 up to D = 7, 2 up to D = 23,
- *                      1 beyond; cfast_kernel 4; cell_kernel 8) */
+ *                      1 beyond; cfast_kernel 4; cell_kernel and cellmm_kernel 8) */
 int kmvp_set_option(kmvp_ctx* ctx, const char* key, int64_t value);
 
 /* BaseAlgorithm.get_memory_usage / get_additional (base.py:35-46): bytes of device

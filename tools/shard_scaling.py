@@ -21,7 +21,7 @@ for world in (1, 2, 4, 8):
     lo, hi = 0, (n + world - 1) // world
     ctx = _lib.Context(0)
     ctx.set_option("same_points_global", 1)
-ctx.set_option("partial_shard", 1)  # a shard without a communicator, on purpose
+    ctx.set_option("partial_shard", 1)  # a shard without a communicator, on purpose
     ctx.set_points(np.ascontiguousarray(ys[lo:hi]), y, _lib.KMVP_F32, j_offset=lo, M_total=n)
     ctx.set_signal(np.ascontiguousarray(bs[lo:hi]))
     ctx.run(kernel, False); ctx.run(kernel, False)
