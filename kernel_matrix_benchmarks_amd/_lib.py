@@ -82,15 +82,26 @@ def load():
 
 
 def dtype_code(precision):
-    """numpy dtype / string ('float32', algos.yaml:157) / 'bfloat16' -> (kmvp_dtype, host numpy dtype)."""
+    """numpy dtype / string ('float32', algos.yaml:157) / 'bfloat16' -> (kmvp_dtype, host numpy dtype).
+    float16 (algos.yaml:157,160): the reference casts its inputs to float16 and lets numpy do float16 arithmetic;
+    here the inputs are ROUNDED to float16 by the plugin (``input_rounding``) and the arithmetic is float32."""
     if isinstance(precision, str) and precision.lower() in ("bfloat16", "bf16"):
         return KMVP_BF16, np.dtype(np.float32)
     dt = np.dtype(precision)
+    if dt == np.float16:
+        return KMVP_F32, np.dtype(np.float32)
     if dt == np.float64:
         return KMVP_F64, dt
     if dt == np.float32:
         return KMVP_F32, dt
     raise NotImplementedError(f"precision {precision!r} is not supported by the MI355X backend")
+
+
+def input_rounding(precision):
+    """dtype the host arrays are rounded to BEFORE the cast to the working precision (None: no extra rounding)."""
+    if isinstance(precision, str) and precision.lower() in ("bfloat16", "bf16"):
+        return None
+    return np.dtype(np.float16) if np.dtype(precision) == np.float16 else None
 
 
 class Context:

@@ -48,6 +48,9 @@ class MI355XProduct(BaseProduct):
             # same failure mode as bruteforce.py:82-85
             raise NotImplementedError(f"MI355XProduct doesn't support kernel {kernel}.")
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)  # NotImplementedError if unknown
+        # precision="float16" (algos.yaml:157): inputs rounded to float16 as the reference casts them
+        # (bruteforce.py:103-111,126), arithmetic in float32 on the GPU
+        self._round = _lib.input_rounding(precision)
         self.device = device
         self.comm = comm
         # fast_sqdists mirrors the reference's flag (bruteforce.py:70,36-49): True = expanded
@@ -67,19 +70,24 @@ class MI355XProduct(BaseProduct):
         self.name = f"MI355XProduct({_precision_name(precision)})" if fast_sqdists is None else (
             f"MI355XProduct({_precision_name(precision)}, fast_sqdists={fast_sqdists})")
 
+    def _cast(self, a):
+        if self._round is not None:
+            a = np.asarray(a, dtype=self._round)
+        return np.ascontiguousarray(a, dtype=self._host_dtype)
+
     # -- untimed -------------------------------------------------------------------
     def prepare_data(self, *, source_points, target_points, same_points=False,
                      density_estimation=False):
         # h5py hands numpy.bool_ attributes over (runner.py:41-43)
         self.same_points = bool(same_points)
         self.density_estimation = bool(density_estimation)
-        y = np.ascontiguousarray(source_points, dtype=self._host_dtype)
+        y = self._cast(source_points)
         self.M, self.D = y.shape
         if self.same_points:
             x = None
             self.N = self.M
         else:
-            x = np.ascontiguousarray(target_points, dtype=self._host_dtype)
+            x = self._cast(target_points)
             self.N = x.shape[0]
         if self._ctx is None:
             self._ctx = _lib.Context(self.device)
@@ -118,7 +126,7 @@ class MI355XProduct(BaseProduct):
             self._ctx.set_signal(None)
             self.E = 1
             return
-        b = np.ascontiguousarray(source_signal, dtype=self._host_dtype)
+        b = self._cast(source_signal)
         if b.ndim == 1:
             b = b.reshape(-1, 1)
         if b.ndim != 2 or b.shape[0] != self.M:
@@ -210,7 +218,8 @@ class MI355XSolver(BaseSolver):
         self.comm = comm  # sharding.Communicator: operator sharded over the sources, vectors replicated
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)
         if self._dtype_code == _lib.KMVP_BF16:
-            raise NotImplementedError("MI355XSolver needs float32 or float64")
+            raise NotImplementedError("MI355XSolver needs float16, float32 or float64")
+        self._round = _lib.input_rounding(precision)  # float16: rounded inputs, float32 operator (scipy promotes too)
         self.device = device
         self.rtol = rtol
         self.maxit = maxit
@@ -221,8 +230,13 @@ class MI355XSolver(BaseSolver):
         self.method = "minres" if kernel == "inverse-distance" else "cg"
         self.name = f"MI355XSolver({_precision_name(precision)}, {self.method}, rtol={rtol:g})"
 
+    def _cast(self, a):
+        if self._round is not None:
+            a = np.asarray(a, dtype=self._round)
+        return np.ascontiguousarray(a, dtype=self._host_dtype)
+
     def prepare_data(self, *, source_points):
-        y = np.ascontiguousarray(source_points, dtype=self._host_dtype)
+        y = self._cast(source_points)
         self.M, self.D = y.shape
         if self._ctx is None:
             self._ctx = _lib.Context(self.device)
@@ -245,7 +259,7 @@ class MI355XSolver(BaseSolver):
         self._ctx.fit(self.kernel)
 
     def prepare_query(self, *, target_signal):
-        a = np.ascontiguousarray(target_signal, dtype=self._host_dtype)
+        a = self._cast(target_signal)
         self._a = a.reshape(-1, 1) if a.ndim == 1 else a
         if self._a.ndim != 2 or self._a.shape[0] != self.M:
             raise ValueError(f"target_signal has shape {a.shape}, expected ({self.M}, E)")

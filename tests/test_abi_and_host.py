@@ -54,8 +54,11 @@ def test_constructor_contract():
         mi355x.MI355XSolver(kernel="laplacian", dimension=3)
     assert mi355x.MI355XSolver(kernel="inverse-distance", dimension=3).method == "minres"
     assert mi355x.MI355XSolver(kernel="gaussian", dimension=3).method == "cg"
-    with pytest.raises(NotImplementedError):
-        mi355x.MI355XProduct(kernel="gaussian", dimension=3, precision="float16")
+    with pytest.raises((NotImplementedError, TypeError)):
+        mi355x.MI355XProduct(kernel="gaussian", dimension=3, precision="int8")
+    p16 = mi355x.MI355XProduct(kernel="gaussian", dimension=3, precision="float16")  # algos.yaml:157
+    assert str(p16) == "MI355XProduct(float16)" and p16._round == np.float16 and p16._host_dtype == np.float32
+    p16.done()
     p = mi355x.MI355XProduct(kernel="gaussian", dimension=3, normalize_rows=True, precision="float32")
     assert p.task == "product" and str(p) == "MI355XProduct(float32)" and p.normalize_rows
     assert isinstance(p, base.BaseProduct) and p.get_additional() == {} and p.get_memory_usage() == 0.0
@@ -76,8 +79,8 @@ def test_no_gpu_means_a_loud_failure_not_a_fallback():
 
 def test_registry_expansion_rules():
     defs = definitions.get_definitions(dataset="product-cube-D3-E1-M1000-N1000-gaussian")
-    assert [d.arguments["precision"] for d in defs] == ["float32", "float64"]
-    d = defs[0]
+    assert [d.arguments["precision"] for d in defs] == ["float16", "float32", "float64"]  # the reference's three (algos.yaml:157-162)
+    d = defs[1]
     assert d.arguments["kernel"] == "gaussian" and d.arguments["dimension"] == 3
     assert d.arguments["normalize_rows"] is False and d.query_argument_groups == [{}]
     assert definitions.algorithm_available(d)

@@ -75,6 +75,40 @@ def test_float32_matches_reference(case, expected):
     assert extra["n_gpus"] == 1 and extra["device_kernel"]
 
 
+@pytest.fixture(scope="module")
+def expected_f16():
+    """Outputs of the reference's own float16 runs (tests/make_golden_f16.py)."""
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "expected_f16.npz")
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_float16_is_at_least_as_accurate_as_the_references_float16(case, expected, expected_f16):
+    """precision="float16" (algos.yaml:157,160): the reference casts points and signal to float16 and lets numpy
+    do float16 arithmetic; the plugin rounds the inputs the same way and computes in float32.  Pinned two ways:
+    (1) against the float64 oracle on the SAME float16-rounded inputs, at the float32 tolerance; (2) against the
+    reference's own float16 output, by the rule used for float32 everywhere in this file: the plugin's distance from
+    the float64 truth is at most 2 x the distance of the REFERENCE's own run in that precision (both carry the
+    rounding of the inputs to float16, ~1e-3; the reference adds float16 arithmetic, which sometimes cancels part)."""
+    y, x, b = golden_cases.make_inputs(case)
+    r16 = lambda a: None if a is None else np.asarray(a, dtype=np.float16).astype(np.float64)
+    truth16 = kmvp_oracle.product(kernel=case["kernel"], source_points=r16(y), target_points=r16(x), source_signal=r16(b),
+                                  normalize_rows=case["normalize_rows"], density_estimation=case["density_estimation"])
+    got, extra = run_plugin(case, y, x, b, "float16")
+    assert got.shape == truth16.shape
+    assert np.array_equal(row_finite(got), row_finite(truth16)), "non-finite rows differ (coincident float16 points)"
+    assert rel_err(got, truth16) <= TOL32, rel_err(got, truth16)
+    truth = expected[f"{case['name']}/f64"]
+    ref16 = expected_f16[f"{case['name']}/f16"].astype(np.float64)
+    both = row_finite(truth) & row_finite(ref16) & row_finite(got)
+    if both.any():
+        mine, theirs = rel_err(got[both], truth[both]), rel_err(ref16[both], truth[both])
+        assert mine <= 2 * theirs + TOL32, (mine, theirs)
+
+
 LOW_D_E1 = [c for c in CASES if c["D"] <= 39 and (c["E"] == 1 or c["density_estimation"])]
 
 
@@ -1069,7 +1103,7 @@ def test_runner_drives_the_headline_dataset_under_its_reference_name(tmp_path):
     stored = runner.run_dataset(name, hardware="GPU", runs=2, data_root=str(tmp_path / "data"),
                                 results_root=str(tmp_path / "results"), verbose=False)
     by_name = {attrs["name"]: (attrs, result) for _, attrs, result in stored}
-    assert sorted(by_name) == ["MI355XProduct(float32)", "MI355XProduct(float64)"]
+    assert sorted(by_name) == ["MI355XProduct(float16)", "MI355XProduct(float32)", "MI355XProduct(float64)"]
     f, D = datasets.get_dataset(name, root=str(tmp_path / "data"))
     try:
         y = np.asarray(f["source_points"][:])
@@ -1263,7 +1297,7 @@ def test_runner_end_to_end_on_gpu(tmp_path):
     data_root, results_root = str(tmp_path / "data"), str(tmp_path / "results")
     stored = runner.run_dataset(name, hardware="GPU", runs=2, data_root=data_root,
                                 results_root=results_root, verbose=False)
-    assert len(stored) == 2  # float32 and float64 run-group entries of algos.yaml
+    assert len(stored) == 3  # float16, float32 and float64 run-group entries of algos.yaml
     # the generated dataset follows the reference's recipe and its truth is the oracle's answer
     f, D = datasets.get_dataset(name, root=data_root)
     try:

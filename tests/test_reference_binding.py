@@ -91,13 +91,15 @@ def test_reference_loader_instantiates_the_plugin_from_the_integration_stub(tmp_
     assert run.returncode == 0, run.stdout + run.stderr
     out = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
 
-    assert out["counts"] == [2, 2, 1, 0]  # float32 + float64 products, the same as attention, one solver; nothing on CPU
-    assert out["status"] == ["AVAILABLE"] * 5
+    assert out["counts"] == [3, 3, 1, 0]  # float16 / 32 / 64 products, the same as attention, one solver; nothing on CPU
+    assert out["status"] == ["AVAILABLE"] * 7
     assert out["modules"] == ["kernel_matrix_benchmarks.algorithms.mi355x"]  # loaded THROUGH the stub
     assert out["using_reference_bases"] and out["same_class_objects"]
     assert out["unknown_kernel"] == "NotImplementedError"
-    p32, p64, a32, a64, s64 = out["instances"]
-    for inst, name, precision, kernel, norm in ((p32, "MI355XProduct(float32)", "float32", "gaussian", False),
+    p16, p32, p64, a16, a32, a64, s64 = out["instances"]
+    for inst, name, precision, kernel, norm in ((p16, "MI355XProduct(float16)", "float16", "gaussian", False),
+                                                (a16, "MI355XProduct(float16)", "float16", "absolute-exponential", True),
+                                                (p32, "MI355XProduct(float32)", "float32", "gaussian", False),
                                                 (p64, "MI355XProduct(float64)", "float64", "gaussian", False),
                                                 (a32, "MI355XProduct(float32)", "float32", "absolute-exponential", True),
                                                 (a64, "MI355XProduct(float64)", "float64", "absolute-exponential", True)):
