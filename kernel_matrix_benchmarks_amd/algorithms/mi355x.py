@@ -26,7 +26,30 @@ from kernel_matrix_benchmarks_amd import _lib
 from kernel_matrix_benchmarks_amd.algorithms.base import BaseProduct, BaseSolver
 from kernel_matrix_benchmarks_amd import sharding
 
-SUPPORTED_KERNELS = ("gaussian", "absolute-exponential", "inverse-distance")
+SUPPORTED_KERNELS = ("gaussian", "absolute-exponential", "inverse-distance", "exp-dot")
+# "exp-dot": k(x, y) = exp(<x, y>), the transformer attention kernel the reference's README defines
+# (README.md:51-59) but its plugins do not implement (bruteforce.py:18-22 has the other three): parity
+# unpinned, checked against a direct numpy evaluation only.  Computed through the identity
+#     exp(<x, y>) = exp(|x|^2 / 2) * exp(-|x/sqrt2 - y/sqrt2|^2) * exp(|y|^2 / 2)
+# i.e. a GAUSSIAN product on the points / sqrt(2) with the signal weighted by w_j = exp(|y_j|^2/2 - c)
+# (c = max_j |y_j|^2/2, so w <= 1) -- every Gaussian kernel of the library serves it, the cell form included.
+# Row-normalised ("softmax attention"): (K (w b)) / (K w), the factor of the target cancels; plain products
+# multiply it back in float64.  Valid while |y_j|^2/2 spans less than the exponent range of the working
+# precision (~80 for float32); an online-max formulation would lift that and is not built.
+SQRT_HALF = 0.7071067811865476
+
+
+def _sq_norms_on_device(p_scaled, bf16):
+    """|p'|^2 in float64 of the SCALED points exactly as the device will see them (float32 / float64 values as cast;
+    bfloat16: rounded to nearest even as the packing kernels round) -- so that the weights exp(|y'|^2) and the
+    Gaussian exp(-|x' - y'|^2) are about the same points and the identity holds to rounding of the arithmetic only."""
+    q = np.asarray(p_scaled)
+    if bf16:
+        u = np.ascontiguousarray(q, dtype=np.float32).view(np.uint32)
+        u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+        q = u.view(np.float32)
+    q = q.astype(np.float64)
+    return np.sum(q * q, axis=1)
 
 
 def _precision_name(precision):
@@ -47,6 +70,8 @@ class MI355XProduct(BaseProduct):
         if kernel not in SUPPORTED_KERNELS:
             # same failure mode as bruteforce.py:82-85
             raise NotImplementedError(f"MI355XProduct doesn't support kernel {kernel}.")
+        self._dot = kernel == "exp-dot"
+        self._device_kernel_fn = "gaussian" if self._dot else kernel
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)  # NotImplementedError if unknown
         # precision="float16" (algos.yaml:157): inputs rounded to float16 as the reference casts them
         # (bruteforce.py:103-111,126), arithmetic in float32 on the GPU
@@ -81,6 +106,18 @@ class MI355XProduct(BaseProduct):
         # h5py hands numpy.bool_ attributes over (runner.py:41-43)
         self.same_points = bool(same_points)
         self.density_estimation = bool(density_estimation)
+        if self._dot:
+            # the caller's points in the working precision first (what the kernel is defined on), then the identity
+            ys = np.asarray(self._cast(source_points), dtype=np.float64)
+            xs = ys if self.same_points else np.asarray(self._cast(target_points), dtype=np.float64)
+            source_points = ys * SQRT_HALF
+            target_points = xs * SQRT_HALF
+            bf16 = self._dtype_code == _lib.KMVP_BF16
+            hy = _sq_norms_on_device(self._cast(source_points), bf16)   # |y/sqrt2|^2 = |y|^2 / 2
+            hx = hy if self.same_points else _sq_norms_on_device(self._cast(target_points), bf16)
+            shift = float(np.max(hy)) if len(hy) else 0.0
+            self._w = np.exp(hy - shift).reshape(-1, 1)   # source weights, <= 1
+            self._hx = hx + shift                         # log of the target factor exp(|x|^2/2 + c)
         y = self._cast(source_points)
         self.M, self.D = y.shape
         if self.same_points:
@@ -104,7 +141,7 @@ class MI355XProduct(BaseProduct):
             lo, hi = self._shard
             # Gaussian (no index-based rule): shard the sources cell by cell instead of in the caller's
             # order -- every rank derives the same permutation from the full cloud it was handed
-            self._order = (sharding.spatial_order(y) if self.kernel == "gaussian" and self._host_dtype == np.float32
+            self._order = (sharding.spatial_order(y) if self._device_kernel_fn == "gaussian" and self._host_dtype == np.float32
                            else None)
             if self._order is not None:
                 targets = y if x is None else x
@@ -122,6 +159,21 @@ class MI355XProduct(BaseProduct):
             self._ctx.set_points(y, x, self._dtype_code)
 
     def prepare_query(self, *, source_signal):
+        if self._dot:
+            # weighted signal [w b | w]: numerator columns and (normalised rows) the denominator column
+            b = np.ones((self.M, 1)) if self.density_estimation else np.asarray(self._cast(source_signal), dtype=np.float64)
+            if b.ndim == 1:
+                b = b.reshape(-1, 1)
+            if b.ndim != 2 or b.shape[0] != self.M:
+                raise ValueError(f"source_signal has shape {b.shape}, expected ({self.M}, E)")
+            self.E = b.shape[1]
+            cols = [self._w * b] + ([self._w] if self.normalize_rows else [])
+            wb = np.ascontiguousarray(np.concatenate(cols, axis=1), dtype=self._host_dtype)
+            lo, hi = self._shard
+            if self._order is not None:
+                wb = wb[self._order]
+            self._ctx.set_signal(np.ascontiguousarray(wb[lo:hi]))
+            return
         if self.density_estimation:
             self._ctx.set_signal(None)
             self.E = 1
@@ -139,17 +191,23 @@ class MI355XProduct(BaseProduct):
         self._ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
 
     def get_result(self):
+        if self._dot:
+            if self.normalize_rows:
+                res = self._ctx.get_result(self.N, self.E + 1)
+                return np.ascontiguousarray(res[:, : self.E] / res[:, self.E:])  # exp(|x_i|^2/2) cancels
+            res = self._ctx.get_result(self.N, self.E)
+            return np.ascontiguousarray(res * np.exp(self._hx).reshape(-1, 1))
         return self._ctx.get_result(self.N, self.E)
 
     # -- timed ---------------------------------------------------------------------
     def fit(self):
         """The kernel matrix is never formed; what the points alone determine (grid, cell order and tile
         lists of the Gaussian cell kernels) is built here, as the reference builds its structure in fit()."""
-        self._ctx.fit(self.kernel)
+        self._ctx.fit(self._device_kernel_fn)
 
     def query(self):
         # synchronous: the device (and the all-reduce) is done when this returns
-        self._ctx.run(self.kernel, self.normalize_rows)
+        self._ctx.run(self._device_kernel_fn, self.normalize_rows and not self._dot)
         self.res = None  # the result stays on the device until get_result()
 
     # -- bookkeeping ---------------------------------------------------------------
@@ -227,6 +285,8 @@ class MI355XSolver(BaseSolver):
         self.iterations = 0
         self.residual = float("nan")
         self.converged = False
+        self._dot = kernel == "exp-dot"  # K = D G D with D = diag(exp(|x|^2/2)), G the Gaussian matrix of the points / sqrt(2)
+        self._device_kernel_fn = "gaussian" if self._dot else kernel
         self.method = "minres" if kernel == "inverse-distance" else "cg"
         self.name = f"MI355XSolver({_precision_name(precision)}, {self.method}, rtol={rtol:g})"
 
@@ -236,6 +296,10 @@ class MI355XSolver(BaseSolver):
         return np.ascontiguousarray(a, dtype=self._host_dtype)
 
     def prepare_data(self, *, source_points):
+        if self._dot:
+            ys = np.asarray(self._cast(source_points), dtype=np.float64)
+            source_points = ys * SQRT_HALF
+            self._hx = _sq_norms_on_device(self._cast(source_points), False)
         y = self._cast(source_points)
         self.M, self.D = y.shape
         if self._ctx is None:
@@ -256,9 +320,11 @@ class MI355XSolver(BaseSolver):
 
     def fit(self):
         """Nothing to factorise; the cell order of the float64 Gaussian operator is built here (kmvp_fit)."""
-        self._ctx.fit(self.kernel)
+        self._ctx.fit(self._device_kernel_fn)
 
     def prepare_query(self, *, target_signal):
+        if self._dot:  # G (D b) = D^-1 a
+            target_signal = np.asarray(target_signal, dtype=np.float64).reshape(self.M, -1) * np.exp(-self._hx).reshape(-1, 1)
         a = self._cast(target_signal)
         self._a = a.reshape(-1, 1) if a.ndim == 1 else a
         if self._a.ndim != 2 or self._a.shape[0] != self.M:
@@ -272,7 +338,9 @@ class MI355XSolver(BaseSolver):
 
     def query(self):
         self.res, self.iterations, self.residual, self.converged = self._ctx.cg_solve(
-            self.kernel, self._a, self.rtol, self.maxit)
+            self._device_kernel_fn, self._a, self.rtol, self.maxit)
+        if self._dot:
+            self.res = self.res * np.exp(-self._hx).reshape(-1, 1)  # b = D^-1 (D b)
 
     def get_memory_usage(self):
         return 0.0 if self._ctx is None else self._ctx.device_bytes / 1024

@@ -156,6 +156,26 @@ def product(
     return np.ascontiguousarray(res, dtype=np.float64)
 
 
+def exp_dot_product(*, source_points, target_points=None, source_signal=None, normalize_rows=False, block_rows=2048):
+    """a_i = sum_j exp(<x_i, y_j>) b_j [/ sum_j exp(<x_i, y_j>)] in float64, evaluated directly.
+
+    PARITY UNPINNED: the kernel is defined only in the reference's README (README.md:51-59, "an exponential kernel
+    k(x_i, y_j) = exp(<x_i, y_j>)" for attention layers); none of its plugins implements it (bruteforce.py:18-22),
+    so there is no reference output to pin it.  This direct evaluation (row max subtracted before exp, the textbook
+    softmax stabilisation) checks the Gaussian identity the plugin uses."""
+    y = np.asarray(source_points, dtype=np.float64)
+    x = y if target_points is None else np.asarray(target_points, dtype=np.float64)
+    b = np.ones((y.shape[0], 1)) if source_signal is None else np.asarray(source_signal, dtype=np.float64)
+    out = np.empty((x.shape[0], b.shape[1]))
+    for r0 in range(0, x.shape[0], block_rows):
+        s = x[r0 : r0 + block_rows] @ y.T
+        m = s.max(axis=1, keepdims=True)
+        p = np.exp(s - m)
+        num = p @ b
+        out[r0 : r0 + block_rows] = num / p.sum(axis=1, keepdims=True) if normalize_rows else num * np.exp(m)
+    return out
+
+
 def kernel_matrix(*, kernel, source_points, target_points=None, fast_sqdists=False):
     """Dense K (N,M), bruteforce.py:25-58.  Small shapes only."""
     y = source_points

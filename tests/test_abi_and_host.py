@@ -52,6 +52,11 @@ def test_constructor_contract():
         mi355x.MI355XProduct(kernel="laplacian", dimension=3)
     with pytest.raises(NotImplementedError):
         mi355x.MI355XSolver(kernel="laplacian", dimension=3)
+    # README.md:51-59's attention kernel exp(<x, y>): served through the Gaussian identity
+    dot = mi355x.MI355XProduct(kernel="exp-dot", dimension=64, normalize_rows=True, precision="bfloat16")
+    assert dot._device_kernel_fn == "gaussian" and dot.kernel == "exp-dot"
+    dot.done()
+    assert datasets.parse_name("attention-cube-D64-E64-M65536-N65536-exp-dot")["kernel"] == "exp-dot"
     assert mi355x.MI355XSolver(kernel="inverse-distance", dimension=3).method == "minres"
     assert mi355x.MI355XSolver(kernel="gaussian", dimension=3).method == "cg"
     with pytest.raises((NotImplementedError, TypeError)):

@@ -109,6 +109,72 @@ def test_float16_is_at_least_as_accurate_as_the_references_float16(case, expecte
         assert mine <= 2 * theirs + TOL32, (mine, theirs)
 
 
+def test_exp_dot_attention_matches_direct_evaluation():
+    """k(x, y) = exp(<x, y>) (README.md:51-59; PARITY UNPINNED: no reference plugin implements it) through the
+    Gaussian identity, against a direct float64 evaluation: softmax attention (row-normalised, E value channels),
+    plain products, densities; D = 3 (cell form at 4e4 points), 16, 64 (bf16 matrix-core tiles); targets != sources;
+    key norms spanning |y|^2/2 up to ~60."""
+    rs = np.random.RandomState(99)
+    shapes = [(3, 40000, 40000, 4, "float32", 1.0, "cellmm_kernel"), (16, 700, 900, 8, "float32", 1.0, None),
+              (16, 700, 900, 8, np.float64, 2.5, None), (64, 1024, 2048, 64, "float32", 0.35, None),
+              (64, 1024, 2048, 64, "bfloat16", 0.35, None), (3, 500, 300, 1, "float16", 1.0, None)]
+    for D, N, M, E, precision, spread, want_kernel in shapes:
+        y = rs.randn(M, D) * spread / np.sqrt(D) * (1.5 if D == 3 else 3.0)
+        x = rs.randn(N, D) * spread / np.sqrt(D) * (1.5 if D == 3 else 3.0)
+        if D == 3:
+            y, x = rs.rand(M, D), rs.rand(N, D)  # a dense cloud: the cell form takes it
+        b = rs.randn(M, E)
+        tol = {"bfloat16": TOL_BF16, "float16": 5e-3}.get(precision, TOL64 * 10 if precision is np.float64 else 2 * TOL32)
+        rows = rs.choice(N, size=min(N, 300), replace=False)
+        for norm in (True, False):
+            algo = MI355XProduct(kernel="exp-dot", dimension=D, normalize_rows=norm, precision=precision)
+            try:
+                algo.prepare_data(source_points=y, target_points=x, same_points=False)
+                algo.fit()
+                algo.prepare_query(source_signal=b)
+                algo.query()
+                got = algo.get_result()
+                kname = algo.device_kernel
+            finally:
+                algo.done()
+            want = kmvp_oracle.exp_dot_product(source_points=y, target_points=x[rows], source_signal=b, normalize_rows=norm)
+            assert got.shape == (N, E) and got.dtype == np.float64
+            assert rel_err(got[rows], want) <= tol, (D, precision, norm, kname, rel_err(got[rows], want))
+            if want_kernel:
+                assert kname == want_kernel, kname
+            if norm:  # softmax rows are convex combinations of the value rows
+                assert got.min() >= b.min() - 1e-3 and got.max() <= b.max() + 1e-3
+    # density (b = 1) and the all-ones shortcut of normalised densities; same_points
+    y = rs.randn(400, 5) * 0.6
+    for norm in (False, True):
+        algo = MI355XProduct(kernel="exp-dot", dimension=5, normalize_rows=norm, precision=np.float64)
+        try:
+            algo.prepare_data(source_points=y, target_points=y, same_points=True, density_estimation=True)
+            algo.prepare_query(source_signal=np.ones((400, 1)))
+            algo.query()
+            got = algo.get_result()
+        finally:
+            algo.done()
+        want = kmvp_oracle.exp_dot_product(source_points=y, normalize_rows=norm)
+        assert rel_err(got, want) <= 1e-10
+    # the solver: K b = a with K = exp(<x_i, x_j>) on a small well-separated cloud
+    ys = rs.rand(200, 3) * 5.0
+    b_true = rs.randn(200, 1)
+    a = kmvp_oracle.exp_dot_product(source_points=ys, source_signal=b_true)
+    sol = MI355XSolver(kernel="exp-dot", dimension=3, precision=np.float64, rtol=1e-8, maxit=20000)
+    try:
+        sol.prepare_data(source_points=ys)
+        sol.fit()
+        sol.prepare_query(target_signal=a)
+        sol.query()
+        bs = sol.get_result()
+        info = sol.get_additional()
+    finally:
+        sol.done()
+    back = kmvp_oracle.exp_dot_product(source_points=ys, source_signal=bs)
+    assert info["cg_converged"] and np.linalg.norm(back - a) / np.linalg.norm(a) <= 1e-6, info
+
+
 LOW_D_E1 = [c for c in CASES if c["D"] <= 39 and (c["E"] == 1 or c["density_estimation"])]
 
 
