@@ -189,6 +189,11 @@ double kmvp_last_total_ms(const kmvp_ctx* ctx);
 double kmvp_last_allreduce_ms(const kmvp_ctx* ctx);
 /* name of the pair-loop kernel the last compute call launched (for rocprof matching) */
 const char* kmvp_last_kernel_name(const kmvp_ctx* ctx);
+/* The fastest forms are narrow (kmvp_set_option "fast_sqdists").  When the last product did NOT take the cell form
+ * although kernel, precision and dimension would allow it, this says which condition failed (too few points per
+ * cloud, too few points per grid cell, the radius rule, ...); "" when nothing faster applied.  get_additional()
+ * stores it as "dispatch_note". */
+const char* kmvp_last_dispatch_note(const kmvp_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ SYMBOLS = [
     ("kmvp_last_kernel_ms", _c.c_double, [_c.c_void_p]),
     ("kmvp_last_total_ms", _c.c_double, [_c.c_void_p]),
     ("kmvp_last_kernel_name", _c.c_char_p, [_c.c_void_p]),
+    ("kmvp_last_dispatch_note", _c.c_char_p, [_c.c_void_p]),
 ]
 
 _lib = None
@@ -225,6 +226,10 @@ class Context:
     @property
     def last_kernel_name(self):
         return self._lib.kmvp_last_kernel_name(self._ctx).decode()
+
+    @property
+    def last_dispatch_note(self):
+        return self._lib.kmvp_last_dispatch_note(self._ctx).decode()
 
 
 def comm_unique_id():

@@ -247,6 +247,8 @@ class MI355XProduct(BaseProduct):
             # what RCCL itself saw, and the all-reduce's share of device_total_ms (0 on one GPU)
             "rccl_ranks": self._ctx.rccl_ranks,
             "allreduce_ms": self._ctx.last_allreduce_ms,
+            # "" or why a faster form was not taken (too few points per grid cell, the radius rule, ...)
+            "dispatch_note": self._ctx.last_dispatch_note,
         }
 
     def done(self):

@@ -294,5 +294,6 @@ double kmvp_last_kernel_ms(const kmvp_ctx* c) { return c ? c->last_kernel_ms : 0
 double kmvp_last_total_ms(const kmvp_ctx* c) { return c ? c->last_total_ms : 0.0; }
 double kmvp_last_allreduce_ms(const kmvp_ctx* c) { return c ? c->last_allreduce_ms : 0.0; }
 const char* kmvp_last_kernel_name(const kmvp_ctx* c) { return c ? c->last_kernel_name : ""; }
+const char* kmvp_last_dispatch_note(const kmvp_ctx* c) { return c ? c->note.c_str() : ""; }
 
 }  // extern "C"

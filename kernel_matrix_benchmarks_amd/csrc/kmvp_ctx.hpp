@@ -153,6 +153,7 @@ struct kmvp_ctx {
   int comm_count = 1;                      // ranks the RCCL communicator itself reports (ncclCommCount)
   float last_kernel_ms = 0.f, last_total_ms = 0.f, last_allreduce_ms = 0.f;
   const char* last_kernel_name = "";
+  std::string note;  // why the last product did not take a faster form ("" when it did): kmvp_last_dispatch_note
 };
 
 namespace kmvp {

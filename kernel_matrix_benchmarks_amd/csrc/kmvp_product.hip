@@ -1274,8 +1274,34 @@ int prepare_points(kmvp_ctx* c, int kernel) {
   return KMVP_OK;
 }
 
+// Why a float32 Gaussian product at D <= 3 did not take the cell form (kmvp_last_dispatch_note): the fastest paths
+// are narrow, and a caller who gets 5e12 instead of 3.7e13 pairs/s should be told which condition failed.
+static void note_no_cells(kmvp_ctx* c) {
+  char buf[256];
+  const float sc = scale_for<float>(K_GAUSSIAN);
+  if (c->opt_fast >= 0 && c->opt_fast < 3) {
+    snprintf(buf, sizeof buf, "cell form not considered: fast_sqdists = %d was requested", c->opt_fast);
+  } else if (c->async_product) {
+    snprintf(buf, sizeof buf, "cell form not used inside a solver iteration (float32 operator)");
+  } else if (!(c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2)) {
+    snprintf(buf, sizeof buf, "cell form not taken: squared half-diagonal of the clouds' bounding box %.3g > %.3g (radius rule)",
+             (double)(c->cloud_radius2 * sc * sc), (double)FAST_AUTO_RADIUS2);
+  } else if (c->N < SMALL_PROBLEM_TARGETS || c->M < SMALL_PROBLEM_TARGETS) {
+    snprintf(buf, sizeof buf, "cell form not taken: fewer than %lld points in a cloud (N = %lld, M = %lld)",
+             (long long)SMALL_PROBLEM_TARGETS, (long long)c->N, (long long)c->M);
+  } else if (c->cell_state != 1) {
+    snprintf(buf, sizeof buf, "cell form not taken: the grid does not apply (non-finite box or more than %d cells along an axis)",
+             CELL_MAX_GRID);
+  } else {
+    snprintf(buf, sizeof buf, "cell form not taken: padding the cells' tiles would use %.0f %% of the slots (limit %.0f %%): too few "
+             "points per grid cell", 100.0 * cell_padding(c), 100.0 * CELL_AUTO_MAX_PAD);
+  }
+  c->note = buf;
+}
+
 int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   if (!c) return KMVP_E_INVALID;
+  c->note.clear();
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
   if (!c->have_signal) return fail(c, KMVP_E_INVALID, "kmvp_set_signal has not been called");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1343,10 +1369,13 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       int rc = cell_prepare(c, TT);
       if (rc) return rc;
       if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD) &&
-          cellmm_wlog2(c) <= CMM_MAX_WLOG2)
+          cellmm_wlog2(c) <= CMM_MAX_WLOG2) {
+        c->note.clear();
         return run_product_cellmm(c, sig);
+      }
     }
   }
+  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && c->centre_ver == c->points_ver) note_no_cells(c);
   if (c->dtype == KMVP_F32 && c->D <= FAST_MAX_D && (c->density || c->E == 1) && c->centre_ver == c->points_ver) {
     // "fast_sqdists": squared distances in the expanded form on the matrix cores.
     //   fast_kernel  one centre for the whole cloud: absolute error eps32 (|x'|^2 + |y'|^2) in s
@@ -1371,8 +1400,10 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       if (c->cell_state == 1 && (c->opt_fast >= 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD)) {
         // cellmm_kernel (weights in the operand, sum in the accumulator) where its f16 operands have the range:
         // clouds inside the radius rule; cell_kernel otherwise (wide clouds) or on request (fast_sqdists = 4)
+        c->note.clear();
         if (c->opt_fast != 4 && global_ok && cellmm_wlog2(c) <= CMM_MAX_WLOG2)
           return run_product_cellmm(c, sig);  // normalised rows: a second launch with b = 1 for the denominator
+        if (c->opt_fast != 4) c->note = "cell_kernel instead of cellmm_kernel: the clouds are outside the radius rule (f16 operand range)";
         return run_product_cell(c, sig);
       }
     }
@@ -1389,6 +1420,8 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
         (c->opt_fast == 3 || (double)c->cell_n_tiles * CELL64_TILE <= CELL_AUTO_MAX_PAD * (double)c->N))
       return run_product_cell64(c, sig);
   }
+  if (c->D <= LOWD_MAX_D && !c->density && c->E > LOWD_MAX_E && c->note.empty())
+    c->note = "E > 4 signal columns: the difference form runs once per block of four columns";
   if (c->D <= LOWD_MAX_D && !c->density && c->E > LOWD_MAX_E)  // low D, many signal columns
     return c->dtype == KMVP_F64 ? run_product_blocked<double>(c, kernel, sig) : run_product_blocked<float>(c, kernel, sig);
   if (c->dtype == KMVP_F64) return run_product_t<double>(c, kernel, sig);

@@ -127,6 +127,7 @@ def _install_recorder(dist, log):
         device_bytes = 0
         last_kernel_ms = last_total_ms = last_allreduce_ms = 0.0
         last_kernel_name = "recorder"
+        last_dispatch_note = ""
 
         @property
         def rccl_ranks(self):

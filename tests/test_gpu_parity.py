@@ -331,6 +331,8 @@ def test_cell_kernel_shapes_offsets_and_auto_policy():
         # clouds that fill the cells go to the cell kernels by themselves; 4e4 points in the unit cube
         # (40 per cell of side 0.103: more than 30 % of the tile slots would be padding) stay with fast_kernel
         assert extra["device_kernel"] == ("fast_kernel" if case_no == 4 else cell_name), (case_no, extra)
+        # the caller is told WHY the fastest form was not taken (kmvp_last_dispatch_note), and nothing when it was
+        assert ("too few points per grid cell" in extra["dispatch_note"]) == (case_no == 4), extra
         assert rel_err(auto[rows], want) <= TOL32, (case_no, rel_err(auto[rows], want))
 
 
