@@ -15,8 +15,8 @@
 // target) is carried from source tile to source tile of a source cell:  acc += A_tile(T) x B.  The VALU
 // touches a pair of tiles only to rebuild A for the wave's target cell -- ~27 instructions per source tile
 // and lane, shared by the TT = 8 target tiles of the wave: 3.4 per tile pair instead of 22.5 -- and, once per
-// (target tile, source CELL), to fold the accumulator: its 16 rows summed, one cross-half add, times
-// U_i(S), into an fp64 sum.  The constant term
+// (target tile, source CELL), to fold the accumulator: its 16 rows summed (packed adds, one v_permlane32_swap),
+// the change since the last fold times U_i(S) into an fp64 sum.  The constant term
 // W_j b_j of the bracket does not depend on the target inside a cell: it is summed per lane in fp32 as the
 // rows of A are built and joins the accumulator's row sum at the fold (exact in fp32, where an f16 operand
 // would have needed three more slots).  Every pair is still evaluated -- sixteen multiply-adds per pair on
@@ -110,6 +110,27 @@ __device__ __forceinline__ f16x8 cellmm_target_operand(const f32x4 d, int h) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Cross-lane sums of the fold without LDS round trips (a ds_bpermute costs ~100 cycles of latency, and every wave
+// of the chip reaches a source cell's end at about the same time: nobody is left to hide it).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float cellmm_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+// sum over the 32 lanes of a wave half, as a wave-uniform value (both halves hold the same 32 numbers here)
+__device__ __forceinline__ float cellmm_half_sum(float v) {
+  v += cellmm_dpp<0x111, 0xf>(v);  // row_shr:1
+  v += cellmm_dpp<0x112, 0xf>(v);  // row_shr:2
+  v += cellmm_dpp<0x114, 0xf>(v);  // row_shr:4
+  v += cellmm_dpp<0x118, 0xf>(v);  // row_shr:8: lane 15 of every row of 16 holds the row's sum
+  v += cellmm_dpp<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3: lane 31 holds the sum of lanes 0..31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+}
+// v[lane] + v[lane ^ 32] (v_permlane32_swap)
+__device__ __forceinline__ float cellmm_cross_half_add(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+
 template <int TT>
 __global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(TT >= 8 ? 2 : 1)))
 cellmm_kernel(const CellmmArgs a) {
@@ -147,9 +168,11 @@ cellmm_kernel(const CellmmArgs a) {
 
   f32x16 acc[TT];
   double outd[TT];
+  float vprev[TT];  // row sum of acc[tt] at the last fold
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     outd[tt] = 0.0;
+    vprev[tt] = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[tt][k] = 0.f;
   }
@@ -183,15 +206,12 @@ cellmm_kernel(const CellmmArgs a) {
   float S0 = 0.f;     // sum of W_j b_j over this lane's source row, tiles of the current cell
   float D1[3] = {0.f, 0.f, 0.f};  // log2 e (c_T - c_S)
 
-  // fold of the accumulators of the finished source cell into the fp64 sums
+  // Fold of the finished source cell into the fp64 sums.  The accumulators are NOT reset: they run on over the whole
+  // segment and a cell's share is the difference of their row sums before and after it (`vprev`) -- resetting them
+  // costs 16 v_mov per target tile and fold, a sixth of the fold's instructions; the running sums stay small (the
+  // accumulators hold only the t + t^2/2 part, <= 1.6 % of the kernel values) and add ~1e-8 of rounding.
   auto fold = [&]() {
-    float s0 = S0;
-    s0 += __shfl_xor(s0, 16);
-    s0 += __shfl_xor(s0, 8);
-    s0 += __shfl_xor(s0, 4);
-    s0 += __shfl_xor(s0, 2);
-    s0 += __shfl_xor(s0, 1);
-    s0 *= CMM_TARGET_SCALE;  // the accumulators carry the targets' 2^6
+    const float s0 = cellmm_half_sum(S0) * CMM_TARGET_SCALE;  // the accumulators carry the targets' 2^6
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       const f32x16 d = acc[tt];
@@ -203,11 +223,9 @@ cellmm_kernel(const CellmmArgs a) {
       p0 = p0 + p1;
       p2 = p2 + p3;
       p0 = p0 + p2;
-      float v = p0[0] + p0[1];
-      v += __shfl_xor(v, 32);
-      outd[tt] += (double)(U[tt] * (v + s0));
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc[tt][k] = 0.f;  // the next source cell starts from zero
+      const float v = cellmm_cross_half_add(p0[0] + p0[1]);
+      outd[tt] += (double)(U[tt] * ((v - vprev[tt]) + s0));
+      vprev[tt] = v;
     }
     S0 = 0.f;
   };
