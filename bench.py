@@ -188,7 +188,8 @@ def traffic_from_profile(kname, tag):
         return None, None
     rel = os.path.relpath(files[-1], ROOT)
     data = json.load(open(files[-1]))
-    return data.get("hbm_bytes_per_launch"), {"file": rel, "commit": head_commit(rel), "measured_in_this_run": False,
+    return data.get("hbm_bytes_per_launch"), {"file": rel, "commit": head_commit(rel) or data.get("library_commit"),
+                                              "collected": data.get("collected"), "measured_in_this_run": False,
                                               "note": "rocprofv3 --pmc passes of the same command on another lease; "
                                                       "null when the kernel has no committed profile"}
 

@@ -54,7 +54,11 @@ if main and "FETCH_SIZE" in summary[main]:
               f"- HBM-side write bytes = TCC_EA0_WRREQ x 64    = {write:,.0f}   (WRITE_SIZE x 1024 reads {write_raw:,.0f}: uncalibrated for 8-B/lane stores)",
               f"- traffic (read + write) = {fetch + write:,.0f} bytes",
               f"- L2 hit rate = {hit / (hit + miss) if hit + miss else float('nan'):.4f}"]
+    import subprocess
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     json.dump({"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write,
-               "source": os.path.basename(dst) + ".md"}, open(dst + "_traffic.json", "w"))
+               "source": os.path.basename(dst) + ".md", "library_commit": head,
+               "collected": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_* passes of `python bench.py` (tools/profile_bench.sh)"},
+              open(dst + "_traffic.json", "w"))
 open(dst + ".md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
