@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); 
+"""Config 3 (exp(-r) attention, N = M = 65536, D = 64, E = 64, bf16) against the number of source segments and the
+pipelined / plain kernel: kernel ms (min, mean of 10) and device ms of the whole step."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct
 n, D, E = 65536, 64, 64
