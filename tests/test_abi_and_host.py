@@ -413,3 +413,26 @@ def test_config1_plumbing_at_1e4_on_cpu(tmp_path):
     finally:
         f.close()
     assert err["max"] / np.max(np.abs(truth)) < 1e-12, err
+
+
+def test_bench_roofline_tables_and_committed_profiles():
+    """bench.py's per-kernel roofline table names every pair-loop kernel the library can report for the BASELINE
+    configs, and every config's traffic figure points at a committed rocprofv3 summary of THAT kernel."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)  # no GPU work at import
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for kname, (bound, flops_per_pair, peak, basis) in bench.ROOF.items():
+        assert kname.encode() in blob, f"{kname} is not a kernel of libkmvp.so"
+        assert bound in ("mfma", "valu", "hbm") and flops_per_pair > 0 and peak > 0 and len(basis) > 20
+    assert bench.ROOF["cellmm_kernel"][0] == "mfma" and bench.ROOF["cellmm_kernel"][2] == bench.PEAK_F16_MFMA_TFLOPS == 2500.0
+    for kname, tag in (("cellmm_kernel", "gaussian_1e6_f32"), ("mfma_pipe_kernel", "c3_absexp_bf16"),
+                       ("cfast_kernel", "c4shard_invdist_f32"), ("cell64_kernel", "c5_gaussian_1e5_f64")):
+        traffic, source = bench.traffic_from_profile(kname, tag)
+        assert traffic and traffic > 1e6, (kname, tag)
+        assert os.path.exists(os.path.join(ROOT, source["file"])) and source["measured_in_this_run"] is False
+        md = os.path.join(ROOT, source["file"].replace("_traffic.json", ".md"))
+        assert kname in open(md).read(), md  # the summary is of the same kernel
+    assert bench.traffic_from_profile("no_such_kernel", "gaussian_1e6_f32") == (None, None)
