@@ -219,6 +219,7 @@ cellmm_kernel(const CellmmArgs a) {
 
   int key_s = -2;     // cell of the source tiles the accumulators hold (-2: nothing yet)
   float S0 = 0.f;     // sum of W_j b_j over this lane's source row, tiles of the current cell
+  float S0c = 0.f;    // ... and its running compensation
   float D1[3] = {0.f, 0.f, 0.f};  // log2 e (c_T - c_S)
 
   // Fold of the finished source cell into the fp64 sums.  The accumulators are NOT reset: they run on over the whole
@@ -243,6 +244,7 @@ cellmm_kernel(const CellmmArgs a) {
       vprev[tt] = v;
     }
     S0 = 0.f;
+    S0c = 0.f;
   };
   // a new source cell (wave-uniform): fold the finished one, then D1 and U_i = exp(-|x_i - c_S|^2) for this one
   auto new_cell = [&](const f32x4 cs, int ks) {
@@ -291,7 +293,13 @@ cellmm_kernel(const CellmmArgs a) {
       const float a5 = h ? ef[1] * ef[2] : ef[1];
       const float arg = fmaf(ef[0], D1[0], fmaf(ef[1], D1[1], fmaf(ef[2], D1[2], ef[3])));
       const float wb = kexp2(arg) * bq;  // W_j b_j (x sigma_b); v_exp_f32 runs beside the MFMAs
-      S0 += wb;
+      {  // compensated (Kahan) sum: this constant term is ~98 % of the kernel values, and a plain fp32 sum over the
+         // cell's ~30 tiles was the largest single error of the kernel (max error over 4096 rows 5.7e-7 -> 3.5e-7)
+        const float yk = wb - S0c;
+        const float tk = S0 + yk;
+        S0c = (tk - S0) - yk;
+        S0 = tk;
+      }
       const float u1 = a14[0] * wb, u2 = a14[1] * wb;   // x, y | z, x z   (two-way split below)
       const f16x2 R0 = cellmm_pk(u1, u2);
       const float c1 = (float)R0[0], c2 = (float)R0[1];
