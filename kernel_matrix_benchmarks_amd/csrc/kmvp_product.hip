@@ -239,14 +239,14 @@ int reduce_and_finish(kmvp_ctx* c, int segments, int NE, int64_t N, int64_t n_pa
 //    blocks (256 CUs x 8), which only matters when there are few target tiles;
 //  * the fp64 partial buffer segments * NE * n_pad * 8 bytes stays bounded.
 int choose_segments(const kmvp_ctx* c, int64_t tile_blocks, int64_t m_pad, int NE, int64_t n_pad,
-                    int64_t rec_bytes, int64_t min_seg, bool small = false) {
+                    int64_t rec_bytes, int64_t min_seg, bool small = false, int64_t l2_seg_bytes = 2 << 20,
+                    int64_t big_target_blocks = 16384) {
   int64_t seg;
   if (c->opt_segments > 0) {
     seg = c->opt_segments;
   } else {
-    const int64_t l2_seg_bytes = 2 << 20;
     seg = 8 * std::max<int64_t>(1, (m_pad * rec_bytes + 8 * l2_seg_bytes - 1) / (8 * l2_seg_bytes));
-    const int64_t target_blocks = small ? 4096 : 16384;  // small problems: about two rounds of resident blocks
+    const int64_t target_blocks = small ? 4096 : big_target_blocks;  // small problems: about two rounds of resident blocks
     const int64_t for_parallelism = (target_blocks + tile_blocks - 1) / tile_blocks;
     if (for_parallelism > seg) seg = (for_parallelism + 7) / 8 * 8;
     const int64_t cap_len = std::max<int64_t>(1, m_pad / min_seg);              // segment >= min_seg sources
@@ -931,7 +931,11 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   CellGrid grid;
   cell_load_grid(c, grid);
 
-  int segments = choose_segments(c, tile_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, small ? 1 : 2, small);
+  // segments of <= 3 MiB of source image (one per XCD at a time in its 4 MiB L2) and ~16 rounds of resident
+  // workgroups: 8 at the headline shape.  tools/cellmm_segments.py: 8 ... 32 segments run alike (28.3-28.5 ms),
+  // 4 is slower (29.0); every segment costs n_slots x 8 bytes of partial sums written and read back and one more
+  // pass over the targets, so the fewest that keep the chip full are taken (HBM-side traffic 0.44 -> 0.25 GB).
+  int segments = choose_segments(c, tile_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, small ? 1 : 2, small, 3 << 20, 8192);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
 
