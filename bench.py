@@ -327,6 +327,26 @@ def main():
             d["allreduce_ms"] = 0.0
             return d
 
+        def refined_solve():
+            """The same system by mixed-precision refinement (float64 residuals, float32 CG corrections on the
+            matrix-core operator): an extension, reported beside the plain float64 solve, never as `value`."""
+            ref = MI355XSolver(kernel=kernel, dimension=D, precision=np.float64, device=device, rtol=1e-6, maxit=5000,
+                               refine="float32")
+            try:
+                ref.prepare_data(source_points=y)
+                ref.fit()
+                ref.prepare_query(target_signal=a_rhs)
+                ref.query()
+                t0 = time.perf_counter()
+                ref.query()
+                dt = time.perf_counter() - t0
+                d = ref.get_additional()
+                return {"seconds": dt, "float32_iterations": d["cg_iterations"], "refinement_steps": d["refinement_steps"],
+                        "residual_float64": d["cg_relative_residual"], "converged": d["cg_converged"],
+                        "inner_kernel": d["inner_device_kernel"]}
+            finally:
+                ref.done()
+
         done = algo.done
     else:
         algo = MI355XProduct(kernel=kernel, dimension=D, normalize_rows=normalize, precision=precision, device=device,
@@ -530,6 +550,7 @@ def main():
         if solver:
             out["solver"] = err
             out["config"]["operator_ms"] = operator_ms
+            out["solver"]["mixed_precision_refinement"] = refined_solve()
         out.update(others)
         if not args.no_cpu_baseline and args.gpus == 1:
             if shard is not None:

@@ -270,11 +270,23 @@ class MI355XSolver(BaseSolver):
     matrix (zero diagonal, bruteforce.py:13-14)."""
 
     def __init__(self, *, kernel, dimension, normalize_rows=False, precision=np.float64,
-                 device=0, rtol=1e-6, maxit=10000, comm=None):
+                 device=0, rtol=1e-6, maxit=10000, comm=None, refine=None, inner_rtol=1e-3):
         super().__init__(kernel=kernel, dimension=dimension, normalize_rows=normalize_rows,
                          precision=precision)
         if kernel not in SUPPORTED_KERNELS:
             raise NotImplementedError(f"MI355XSolver doesn't support kernel {kernel}.")
+        # refine="float32" (float64 solves only, an extension: the reference has one dense lstsq): mixed-precision
+        # iterative refinement -- the residual a - K x is formed with the FLOAT64 operator, the correction K d = r is
+        # solved to `inner_rtol` by CG on the FLOAT32 operator (the matrix-core cell form: ~10x cheaper per product),
+        # x += d, until the float64 residual meets rtol.  The answer is judged exactly like the plain float64 solve.
+        if refine not in (None, "float32"):
+            raise ValueError("refine must be None or 'float32'")
+        if refine and (np.dtype(precision) != np.float64 or kernel == "inverse-distance" or comm is not None):
+            raise NotImplementedError("refine='float32' is for single-GPU float64 CG solves (gaussian, absolute-exponential, exp-dot)")
+        self.refine = refine
+        self.inner_rtol = float(inner_rtol)
+        self._ctx32 = None
+        self.outer_iterations = 0
         self.comm = comm  # sharding.Communicator: operator sharded over the sources, vectors replicated
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)
         if self._dtype_code == _lib.KMVP_BF16:
@@ -290,7 +302,8 @@ class MI355XSolver(BaseSolver):
         self._dot = kernel == "exp-dot"  # K = D G D with D = diag(exp(|x|^2/2)), G the Gaussian matrix of the points / sqrt(2)
         self._device_kernel_fn = "gaussian" if self._dot else kernel
         self.method = "minres" if kernel == "inverse-distance" else "cg"
-        self.name = f"MI355XSolver({_precision_name(precision)}, {self.method}, rtol={rtol:g})"
+        self.name = (f"MI355XSolver({_precision_name(precision)}, {self.method}, rtol={rtol:g})" if not refine else
+                     f"MI355XSolver({_precision_name(precision)}, {self.method} + refinement on {refine}, rtol={rtol:g})")
 
     def _cast(self, a):
         if self._round is not None:
@@ -298,11 +311,20 @@ class MI355XSolver(BaseSolver):
         return np.ascontiguousarray(a, dtype=self._host_dtype)
 
     def prepare_data(self, *, source_points):
+        self._prepare_data(source_points)
+        if self.refine:
+            # the same points (after the exp-dot scaling) as float32 in a second context: the inner operator
+            if self._ctx32 is None:
+                self._ctx32 = _lib.Context(self.device)
+            self._ctx32.set_points(np.ascontiguousarray(self._y_device, dtype=np.float32), None, _lib.KMVP_F32)
+
+    def _prepare_data(self, source_points):
         if self._dot:
             ys = np.asarray(self._cast(source_points), dtype=np.float64)
             source_points = ys * SQRT_HALF
             self._hx = _sq_norms_on_device(self._cast(source_points), False)
         y = self._cast(source_points)
+        self._y_device = y
         self.M, self.D = y.shape
         if self._ctx is None:
             self._ctx = _lib.Context(self.device)
@@ -323,6 +345,8 @@ class MI355XSolver(BaseSolver):
     def fit(self):
         """Nothing to factorise; the cell order of the float64 Gaussian operator is built here (kmvp_fit)."""
         self._ctx.fit(self._device_kernel_fn)
+        if self._ctx32 is not None:
+            self._ctx32.fit(self._device_kernel_fn)
 
     def prepare_query(self, *, target_signal):
         if self._dot:  # G (D b) = D^-1 a
@@ -339,10 +363,47 @@ class MI355XSolver(BaseSolver):
             self.maxit = maxit
 
     def query(self):
-        self.res, self.iterations, self.residual, self.converged = self._ctx.cg_solve(
-            self._device_kernel_fn, self._a, self.rtol, self.maxit)
+        if self.refine:
+            self._query_refined()
+        else:
+            self.res, self.iterations, self.residual, self.converged = self._ctx.cg_solve(
+                self._device_kernel_fn, self._a, self.rtol, self.maxit)
         if self._dot:
             self.res = self.res * np.exp(-self._hx).reshape(-1, 1)  # b = D^-1 (D b)
+
+    def _query_refined(self):
+        """Mixed-precision iterative refinement (see __init__).  Every outer step: float64 residual (one product of
+        the float64 context), float32 CG on the scaled residual, float64 update."""
+        a = np.asarray(self._a, dtype=np.float64)
+        anorm = np.linalg.norm(a, axis=0)
+        anorm[anorm == 0] = 1.0
+        x = np.zeros_like(a)
+        r = a.copy()
+        self.iterations, self.outer_iterations, self.converged = 0, 0, False
+        rel = float(np.max(np.linalg.norm(r, axis=0) / anorm))
+        best = rel
+        for _ in range(40):
+            if rel <= self.rtol or self.iterations >= self.maxit:
+                break
+            scale = np.max(np.abs(r), axis=0)
+            scale[scale == 0] = 1.0  # (a power-of-two free scaling is not needed: float32 has the range, this keeps it centred)
+            d, iters, _, _ = self._ctx32.cg_solve(self._device_kernel_fn, np.ascontiguousarray(r / scale, dtype=np.float32),
+                                                 self.inner_rtol, max(1, self.maxit - self.iterations))
+            self.iterations += iters
+            self.outer_iterations += 1
+            x_new = x + d * scale
+            self._ctx.set_signal(x_new)
+            self._ctx.run(self._device_kernel_fn, False)
+            r_new = a - self._ctx.get_result(self.M, a.shape[1])
+            rel_new = float(np.max(np.linalg.norm(r_new, axis=0) / anorm))
+            if not np.isfinite(rel_new) or rel_new > 0.9 * best:
+                # the float32 correction did not help (inner tolerance beyond what a float32 operator can reach on
+                # this matrix): keep the last good iterate and say so through `converged`
+                break
+            x, r, rel = x_new, r_new, rel_new
+            best = rel
+        self.res, self.residual = x, rel
+        self.converged = bool(np.isfinite(rel) and rel <= 1.5 * self.rtol)
 
     def get_memory_usage(self):
         return 0.0 if self._ctx is None else self._ctx.device_bytes / 1024
@@ -353,12 +414,18 @@ class MI355XSolver(BaseSolver):
         if self._ctx is not None:
             extra["device_kernel"] = self._ctx.last_kernel_name  # the operator's pair-loop kernel
             extra["rccl_ranks"] = self._ctx.rccl_ranks
+        if self.refine and self._ctx32 is not None:
+            extra["refinement_steps"] = self.outer_iterations
+            extra["inner_device_kernel"] = self._ctx32.last_kernel_name
         return extra
 
     def done(self):
         if self._ctx is not None:
             self._ctx.close()
             self._ctx = None
+        if getattr(self, "_ctx32", None) is not None:
+            self._ctx32.close()
+            self._ctx32 = None
 
     def __del__(self):
         try:

@@ -1285,8 +1285,6 @@ static void note_no_cells(kmvp_ctx* c) {
   const float sc = scale_for<float>(K_GAUSSIAN);
   if (c->opt_fast >= 0 && c->opt_fast < 3) {
     snprintf(buf, sizeof buf, "cell form not considered: fast_sqdists = %d was requested", c->opt_fast);
-  } else if (c->async_product) {
-    snprintf(buf, sizeof buf, "cell form not used inside a solver iteration (float32 operator)");
   } else if (!(c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2)) {
     snprintf(buf, sizeof buf, "cell form not taken: squared half-diagonal of the clouds' bounding box %.3g > %.3g (radius rule)",
              (double)(c->cloud_radius2 * sc * sc), (double)FAST_AUTO_RADIUS2);
@@ -1362,7 +1360,7 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   }
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
-  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->density && c->E > 1 && !c->async_product &&
+  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->density && c->E > 1 &&
       c->centre_ver == c->points_ver && (c->opt_fast == 3 || c->opt_fast < 0)) {
     // several signal columns (low-D attention with E value channels): one cellmm_kernel launch per column where the
     // cell form applies (same rule as for E = 1 below)
@@ -1396,7 +1394,10 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     const bool centred_ok = c->D <= CFAST_MAX_D && (kernel != K_INVDIST || (same && c->N == c->m_total));
     // cell_kernel: exp() range-reduced by grid cells, the polynomial remainder on the matrix cores
     // (Gaussian, D <= 3).  auto: when the clouds fill the cells well enough that padding stays small.
-    if (kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->async_product &&
+    // (also inside a solver iteration: grid, cell order and tile lists belong to the points and were built by
+    // kmvp_fit or by the first product -- long before a burst of iterations is captured into a hipGraph -- and the
+    // launches of the cell paths themselves are asynchronous)
+    if (kernel == K_GAUSSIAN && c->D <= CELL_MAX_D &&
         (c->opt_fast >= 3 || (c->opt_fast < 0 && global_ok && c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
       const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : 0);  // 0: by the padding
       int rc = cell_prepare(c, TT);

@@ -1119,6 +1119,42 @@ def test_config5_gaussian_cg_solver_at_1e5_float64():
     print(f"config 5: {info['cg_iterations']} iterations, residual {info['cg_relative_residual']:.2e}, rows {res_rows:.2e}")
 
 
+def test_mixed_precision_refinement_reaches_the_float64_residual():
+    """MI355XSolver(refine="float32") (an extension; the reference has one dense lstsq): float64 residuals, float32 CG
+    corrections on the matrix-core operator.  Judged like the plain float64 solve: true residual <= 1.5 rtol, checked
+    on 256 oracle rows; an inner tolerance the float32 operator cannot reach must end as NOT converged with the last
+    good iterate, never with garbage."""
+    n = 100_000  # config 5's cloud: dense enough for the float32 cell form (cellmm_kernel) as inner operator
+    y, b = kmvp_oracle.uniform_cube(n, 3)
+    a = run_plugin(dict(kernel="gaussian", D=3), y, None, b, np.float64)[0]
+    rows = np.random.RandomState(3).choice(n, size=256, replace=False)
+    out = {}
+    for inner in (1e-3, 1e-6):
+        sol = MI355XSolver(kernel="gaussian", dimension=3, precision=np.float64, rtol=1e-6, maxit=3000, refine="float32",
+                           inner_rtol=inner)
+        try:
+            sol.prepare_data(source_points=y)
+            sol.fit()
+            sol.prepare_query(target_signal=a)
+            sol.query()
+            out[inner] = (sol.get_result(), sol.get_additional())
+        finally:
+            sol.done()
+    x, info = out[1e-3]
+    assert info["cg_converged"] and info["cg_relative_residual"] <= 1.5e-6, info
+    assert info["inner_device_kernel"] == "cellmm_kernel" and info["refinement_steps"] >= 2, info
+    Kx = c_oracle.product(kernel="gaussian", source_points=y, source_signal=x, rows=rows)
+    assert np.linalg.norm(Kx - a[rows]) / np.linalg.norm(a[rows]) <= 5e-6
+    x6, info6 = out[1e-6]
+    assert np.isfinite(x6).all() and np.isfinite(info6["cg_relative_residual"])
+    if not info6["cg_converged"]:
+        assert info6["cg_relative_residual"] <= 1.0  # the last good iterate (at worst x = 0), not a diverged one
+    with pytest.raises(NotImplementedError):
+        MI355XSolver(kernel="inverse-distance", dimension=3, precision=np.float64, refine="float32")
+    with pytest.raises(NotImplementedError):
+        MI355XSolver(kernel="gaussian", dimension=3, precision="float32", refine="float32")
+
+
 def test_solver_verdict_is_the_true_residual_and_never_nan():
     """KMVP_OK only for a finite TRUE residual <= 1.5 rtol.  A NaN right-hand side, or an operator
     with inf entries (inverse-distance with a duplicated point under MINRES), is not a success."""
