@@ -69,8 +69,9 @@ struct CellArgs {
   const float* xd;           // targets [n_slots][4]: d_x, d_y, d_z, 0 (cell-sorted, tiles padded)
   const float* tmeta;        // target tiles [n_slots / 32][4]: c_x, c_y, c_z, cell key (bits; bit 30: empty tile)
   const unsigned char* img;  // source stages [m_stages][CELL_STAGE_BYTES]
-  double* part;              // partial sums [segments][NE][n_slots]
-  int64_t n_slots;
+  double* part;              // partial sums of THIS launch's tiles [segments][NE][n_slots]
+  int64_t n_slots;           // slots (tiles x 32) of this launch
+  int64_t tile_base;         // first target tile of this launch (0: the list of whole groups; behind it: the leftover tiles)
   int64_t m_stages;
   int64_t seg_stages;
   int segments;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31;
   const int h = lane >> 5;
-  const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
+  const int64_t tile0 = a.tile_base + ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
 
   // TT = 8 keeps the targets' offsets in LDS and re-reads them when U is recomputed (once per source
   // cell) instead of holding them: 24 registers decide between three and four waves per SIMD there
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cell_kernel(const CellArgs a) {
     for (int e = 0; e < NE; ++e) {
       double v = accd[tt][e] + (double)acc[tt][e];
       v += __shfl_xor(v, 32);
-      if (h == 0) a.part[((int64_t)seg * NE + e) * a.n_slots + (tile0 + tt) * CELL_TILE + r] = v;
+      if (h == 0) a.part[((int64_t)seg * NE + e) * a.n_slots + (tile0 + tt - a.tile_base) * CELL_TILE + r] = v;
     }
 }
 

@@ -76,8 +76,9 @@ struct CellmmArgs {
   const float* tmeta;        // target tiles [n_slots / 32][4]: c_x, c_y, c_z, cell key (bit 30: empty tile)
   const unsigned char* img;  // source stages [m_stages][CMM_STAGE_BYTES]
   const float* scale;        // [0] sigma_b, [1] 1 / (sigma_b * 2^6)
-  double* part;              // partial sums [segments][1][n_slots]
-  int64_t n_slots;
+  double* part;              // partial sums of THIS launch's tiles [segments][n_slots]
+  int64_t n_slots;           // slots (tiles x 32) of this launch
+  int64_t tile_base;         // first target tile of this launch (0: the list of whole groups; behind it: the leftover tiles)
   int64_t m_stages;
   int64_t seg_stages;
   int segments;
@@ -160,7 +161,7 @@ cellmm_kernel(const CellmmArgs a) {
   const int wave = threadIdx.x >> 6;
   const int r = lane & 31;
   const int h = lane >> 5;
-  const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
+  const int64_t tile0 = a.tile_base + ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
 
   // TT = 8 keeps the targets' offsets in LDS (needed again only when U is recomputed, once per source cell)
   constexpr bool HOLD_D = TT < 8;
@@ -332,7 +333,7 @@ cellmm_kernel(const CellmmArgs a) {
   const double inv = (double)a.scale[1];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
-    if (h == 0) a.part[(int64_t)seg * a.n_slots + (tile0 + tt) * CELL_TILE + r] = outd[tt] * inv;
+    if (h == 0) a.part[(int64_t)seg * a.n_slots + (tile0 + tt - a.tile_base) * CELL_TILE + r] = outd[tt] * inv;
 }
 
 hipError_t launch_cellmm_gaussian(int TT, const CellmmArgs& args, dim3 grid, hipStream_t stream, const char** kernel_name);

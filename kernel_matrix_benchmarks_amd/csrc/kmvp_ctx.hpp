@@ -142,7 +142,8 @@ struct kmvp_ctx {
   int cell_tt = 0, cell_tt_req = 0;       // target tiles per wavefront the target tile list was padded for; as requested (0 = auto)
   float cell_lo[3] = {0.f, 0.f, 0.f}, cell_hh[3] = {1.f, 1.f, 1.f};  // grid origin and cell sides per axis
   int cell_g[3] = {1, 1, 1};
-  int64_t cell_n_tiles = 0, cell_m_tiles = 0;  // real tiles of 32 (targets / sources)
+  int64_t cell_n_tiles = 0, cell_m_tiles = 0;  // tiles of 32 (targets: both lists, padded to workgroups / sources)
+  int64_t cell_n_main = 0, cell_n_rest = 0;    // float32 cell kernels: target tiles in groups of cell_tt / leftover tiles in groups of 2
   float cloud_radius2 = INFINITY;          // squared half-diagonal of the clouds' bounding box
   uint64_t centre_ver = 0;
 

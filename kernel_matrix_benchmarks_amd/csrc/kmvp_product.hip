@@ -98,6 +98,18 @@ __global__ void reduce_segments_kernel(const double* __restrict__ part, double* 
   sums[q] = v;
 }
 
+// The same for one launch's REGION of partial sums [segment][column][region_slots] (the float32 cell kernels run two
+// launches with different numbers of segments): sums[e][slot_base + sl] = sum over segments, sums being [column][n_slots].
+__global__ void reduce_region_kernel(const double* __restrict__ part, double* __restrict__ sums, int64_t region_slots,
+                                     int NE, int segments, int64_t n_slots, int64_t slot_base) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (int64_t)NE * region_slots) return;
+  const int64_t e = q / region_slots, sl = q % region_slots;
+  double v = 0.0;
+  for (int s = 0; s < segments; ++s) v += part[((int64_t)s * NE + e) * region_slots + sl];
+  sums[e * n_slots + slot_base + sl] = v;
+}
+
 // One launch for the single-GPU epilogue: out[i*E + e] = sum over segments (index order) of
 // part[s][e][i], divided by the same sum of column E when normalised.  Same additions in the
 // same order as reduce_segments_kernel + finish_kernel.
@@ -725,6 +737,79 @@ int cell_tiles(kmvp_ctx* c, const std::vector<unsigned>& keys, int mult, kmvp_ct
   return KMVP_OK;
 }
 
+// Target tiles of the float32 cell kernels, in TWO lists that share one array.  A wavefront owns TT tiles of ONE cell,
+// so a cell of `tiles` tiles used to be padded to a multiple of TT with empty tiles -- at the headline shape (cells of
+// 1000 +- 32 points: 32 tiles, or 33-34 for a fifth of them) 5.6 % of all tile pairs were such padding, and the kernel
+// is bound by the matrix pipe.  Now a cell's tiles are split: whole groups of TT go to the MAIN list; a remainder of at
+// most TT/2 tiles goes to the REST list in groups of two (a larger remainder is still padded to a whole group: the
+// second launch with two tiles per wavefront is ~1.6x less efficient per tile).  Both lists are padded to whole
+// workgroups (4 wavefronts) with empty tiles that repeat the preceding key.  Layout as cell_tiles().
+int cell_tiles_split(kmvp_ctx* c, const std::vector<unsigned>& keys, int TT, kmvp_ctx::DevBuf& grp, int64_t* n_main,
+                     int64_t* n_rest) {
+  const int64_t n = (int64_t)keys.size();
+  const int RT = 2;  // tiles per wavefront of the second launch
+  std::vector<int> start, count, rstart, rcount;
+  std::vector<unsigned> gkey, rkey;
+  start.reserve((size_t)n / 24 + 64);
+  count.reserve((size_t)n / 24 + 64);
+  gkey.reserve((size_t)n / 24 + 64);
+  for (int64_t p = 0; p < n;) {
+    int64_t e = p + 1;
+    while (e < n && keys[(size_t)e] == keys[(size_t)p]) ++e;
+    const int64_t tiles = (e - p + CELL_TILE - 1) / CELL_TILE;
+    const int64_t rem = tiles % TT;
+    const bool split = TT > RT && rem > 0 && rem <= TT / 2;
+    const int64_t main_tiles = split ? tiles - rem : tiles;
+    int64_t t = p, k = 0;
+    for (; k < main_tiles; ++k, t += CELL_TILE) {
+      start.push_back((int)t);
+      count.push_back((int)std::min<int64_t>(CELL_TILE, e - t));
+      gkey.push_back(keys[(size_t)p]);
+    }
+    for (; !split && k % TT; ++k) {  // an unsplit remainder: empty tiles up to a whole group
+      start.push_back((int)p);
+      count.push_back(0);
+      gkey.push_back(keys[(size_t)p]);
+    }
+    if (split) {
+      int64_t r = 0;
+      for (; r < rem; ++r, t += CELL_TILE) {
+        rstart.push_back((int)t);
+        rcount.push_back((int)std::min<int64_t>(CELL_TILE, e - t));
+        rkey.push_back(keys[(size_t)p]);
+      }
+      for (; r % RT; ++r) {
+        rstart.push_back((int)p);
+        rcount.push_back(0);
+        rkey.push_back(keys[(size_t)p]);
+      }
+    }
+    p = e;
+  }
+  auto pad_to = [](std::vector<int>& st, std::vector<int>& ct, std::vector<unsigned>& ky, size_t mult) {
+    while (!st.empty() && st.size() % mult) {
+      st.push_back(st.back());
+      ct.push_back(0);
+      ky.push_back(ky.back());
+    }
+  };
+  pad_to(start, count, gkey, (size_t)TT * WAVES_PER_BLOCK);
+  pad_to(rstart, rcount, rkey, (size_t)RT * WAVES_PER_BLOCK);
+  *n_main = (int64_t)start.size();
+  *n_rest = (int64_t)rstart.size();
+  start.insert(start.end(), rstart.begin(), rstart.end());
+  count.insert(count.end(), rcount.begin(), rcount.end());
+  gkey.insert(gkey.end(), rkey.begin(), rkey.end());
+  const size_t G = start.size();
+  int rc;
+  if ((rc = ensure(c, grp, 3 * std::max<size_t>(G, 1) * sizeof(int)))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(grp.p, start.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync((int*)grp.p + G, count.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync((int*)grp.p + 2 * G, gkey.data(), G * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+  return KMVP_OK;
+}
+
 // The grid of the cell paths: the bounding box (aux) divided, per axis, into the smallest number of equal cells
 // whose side stays within h_max (so boundary cells are as full as the others).  false: more than 1024 cells on an axis.
 bool cell_make_grid(const float* aux, int D, float h_max, CellGrid& grid) {
@@ -807,7 +892,8 @@ int cell_prepare(kmvp_ctx* c, int TT) {
       }
     }
   }
-  if ((rc = cell_tiles(c, keys, TT, c->cell_tgrp, &c->cell_n_tiles))) return rc;
+  if ((rc = cell_tiles_split(c, keys, TT, c->cell_tgrp, &c->cell_n_main, &c->cell_n_rest))) return rc;
+  c->cell_n_tiles = c->cell_n_main + c->cell_n_rest;  // (both lists already padded to whole workgroups)
   c->cell_tt = TT;
   cell_store_grid(c, grid);
   c->cell_state = 1;
@@ -828,18 +914,25 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   const int NE = sig == SIG_NORM ? 2 : 1;
   const int64_t N = c->N;
   const bool small = N < SMALL_PROBLEM_TARGETS;
-  const int TT = c->cell_tt;  // the target tile list was built for it (cell_prepare)
-  const int64_t n_tiles = round_up(c->cell_n_tiles, (int64_t)TT * WAVES_PER_BLOCK);
+  const int TT = c->cell_tt;  // the target tile lists were built for it (cell_prepare)
+  const int64_t n_tiles = c->cell_n_tiles;  // whole groups of TT, then leftover tiles in groups of 2 (cell_tiles_split)
   const int64_t n_slots = n_tiles * CELL_TILE;
-  const int64_t tile_blocks = n_tiles / (TT * WAVES_PER_BLOCK);
+  const int64_t tile_blocks = c->cell_n_main / (TT * WAVES_PER_BLOCK);
+  const int64_t rest_blocks = c->cell_n_rest / (2 * WAVES_PER_BLOCK);
   const int64_t m_stages = (c->cell_m_tiles + CELL_STAGE_TILES - 1) / CELL_STAGE_TILES;
   int rc;
   CellGrid grid;
   cell_load_grid(c, grid);
 
-  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_slots, CELL_STAGE_BYTES, small ? 1 : 4, small);
+  int segments = choose_segments(c, std::max<int64_t>(1, tile_blocks), m_stages, NE, n_slots, CELL_STAGE_BYTES,
+                                 small ? 1 : 4, small);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+  // the launch over the leftover tiles: its own, finer split of the sources and its own region of partial sums
+  int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, NE, n_slots, CELL_STAGE_BYTES, 1, small) : 0;
+  const int64_t rest_seg_stages = rest_blocks > 0 ? (m_stages + rest_segments - 1) / rest_segments : 1;
+  if (rest_blocks > 0) rest_segments = (int)((m_stages + rest_seg_stages - 1) / rest_seg_stages);
+  const int64_t main_slots = c->cell_n_main * CELL_TILE, rest_slots = c->cell_n_rest * CELL_TILE;
 
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
                          c->packed_layout != LAYOUT_CELL || c->packed_T != TT;
@@ -873,30 +966,48 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   c->packed_layout = LAYOUT_CELL;
   c->packed_T = TT;
 
-  if ((rc = ensure(c, c->part, (size_t)segments * NE * n_slots * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->part, ((size_t)segments * main_slots + (size_t)rest_segments * rest_slots) * NE * sizeof(double)))) return rc;
+  double* part_main = (double*)c->part.p;
+  double* part_rest = part_main + (size_t)segments * NE * main_slots;
   CellArgs a;
   a.xd = (const float*)c->xs.p;
   a.tmeta = (const float*)c->cell_tmeta.p;
   a.img = (const unsigned char*)c->rec.p;
-  a.part = (double*)c->part.p;
-  a.n_slots = n_slots;
   a.m_stages = m_stages;
-  a.seg_stages = seg_stages;
-  a.segments = segments;
-  a.tile_blocks = (int)tile_blocks;
   a.chunk_stages = std::max(1, c->opt_chunk / (CELL_TILE * CELL_STAGE_TILES));
-  const dim3 grid_dim((unsigned)(tile_blocks * segments));
   HIP_TRY(c, mark(c, 0));
-  hipError_t le = launch_cell_gaussian(sig, TT, a, grid_dim, c->stream, &c->last_kernel_name);
-  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
+  hipError_t le = hipSuccess;
+  if (tile_blocks > 0) {
+    a.part = part_main;
+    a.n_slots = main_slots;
+    a.tile_base = 0;
+    a.seg_stages = seg_stages;
+    a.segments = segments;
+    a.tile_blocks = (int)tile_blocks;
+    le = launch_cell_gaussian(sig, TT, a, dim3((unsigned)(tile_blocks * segments)), c->stream, &c->last_kernel_name);
+  }
+  if (le == hipSuccess && rest_blocks > 0) {  // the cells' leftover tiles, two per wavefront
+    a.part = part_rest;
+    a.n_slots = rest_slots;
+    a.tile_base = c->cell_n_main;
+    a.seg_stages = rest_seg_stages;
+    a.segments = rest_segments;
+    a.tile_blocks = (int)rest_blocks;
+    le = launch_cell_gaussian(sig, 2, a, dim3((unsigned)(rest_blocks * rest_segments)), c->stream, &c->last_kernel_name);
+  }
+  if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2, 4 or 8");
   HIP_TRY(c, le);
   HIP_TRY(c, mark(c, 1));
 
   // ---- epilogue: segments -> sums in the caller's order, [all-reduce over the source shards], normalise
   if ((rc = ensure(c, c->sums, (size_t)NE * N * sizeof(double)))) return rc;
   if ((rc = ensure(c, c->cell_sums, (size_t)NE * n_slots * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for((int64_t)NE * n_slots)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->cell_sums.p, (int64_t)NE * n_slots, segments);
+  if (tile_blocks > 0)
+    hipLaunchKernelGGL(reduce_region_kernel, dim3(blocks_for((int64_t)NE * main_slots)), dim3(256), 0, c->stream,
+                       (const double*)part_main, (double*)c->cell_sums.p, main_slots, NE, segments, n_slots, (int64_t)0);
+  if (rest_blocks > 0)
+    hipLaunchKernelGGL(reduce_region_kernel, dim3(blocks_for((int64_t)NE * rest_slots)), dim3(256), 0, c->stream,
+                       (const double*)part_rest, (double*)c->cell_sums.p, rest_slots, NE, rest_segments, n_slots, main_slots);
   hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream,
                      (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, NE);
   HIP_TRY(c, hipGetLastError());
@@ -922,10 +1033,11 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   const int NE = sig == SIG_NORM ? E + 1 : E;
   const int64_t N = c->N;
   const bool small = N < SMALL_PROBLEM_TARGETS;
-  const int TT = c->cell_tt;  // the target tile list was built for it (cell_prepare)
-  const int64_t n_tiles = round_up(c->cell_n_tiles, (int64_t)TT * WAVES_PER_BLOCK);
+  const int TT = c->cell_tt;  // the target tile lists were built for it (cell_prepare)
+  const int64_t n_tiles = c->cell_n_tiles;  // whole groups of TT, then leftover tiles in groups of 2 (cell_tiles_split)
   const int64_t n_slots = n_tiles * CELL_TILE;
-  const int64_t tile_blocks = n_tiles / (TT * WAVES_PER_BLOCK);
+  const int64_t tile_blocks = c->cell_n_main / (TT * WAVES_PER_BLOCK);
+  const int64_t rest_blocks = c->cell_n_rest / (2 * WAVES_PER_BLOCK);
   const int64_t m_stages = (c->cell_m_tiles + CMM_STAGE_TILES - 1) / CMM_STAGE_TILES;
   int rc;
   CellGrid grid;
@@ -935,9 +1047,16 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   // workgroups: 8 at the headline shape.  tools/cellmm_segments.py: 8 ... 32 segments run alike (28.3-28.5 ms),
   // 4 is slower (29.0); every segment costs n_slots x 8 bytes of partial sums written and read back and one more
   // pass over the targets, so the fewest that keep the chip full are taken (HBM-side traffic 0.44 -> 0.25 GB).
-  int segments = choose_segments(c, tile_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, small ? 1 : 2, small, 3 << 20, 8192);
+  int segments = choose_segments(c, std::max<int64_t>(1, tile_blocks), m_stages, 1, n_slots, CMM_STAGE_BYTES,
+                                 small ? 1 : 2, small, 3 << 20, 8192);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+  // the launch over the leftover tiles (two per wavefront, few workgroups) gets its own, finer split of the sources --
+  // it is latency-bound per workgroup, so it needs many of them -- and its own region of partial sums
+  int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, 1, small, 3 << 20, 8192) : 0;
+  const int64_t rest_seg_stages = rest_blocks > 0 ? (m_stages + rest_segments - 1) / rest_segments : 1;
+  if (rest_blocks > 0) rest_segments = (int)((m_stages + rest_seg_stages - 1) / rest_seg_stages);
+  const int64_t main_slots = c->cell_n_main * CELL_TILE, rest_slots = c->cell_n_rest * CELL_TILE;
 
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
                          c->packed_layout != LAYOUT_CELLMM || c->packed_T != TT;
@@ -971,21 +1090,17 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   c->packed_layout = LAYOUT_CELLMM;
   c->packed_T = TT;
 
-  if ((rc = ensure(c, c->part, (size_t)segments * n_slots * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->part, ((size_t)segments * main_slots + (size_t)rest_segments * rest_slots) * sizeof(double)))) return rc;
   if ((rc = ensure(c, c->sums, (size_t)NE * N * sizeof(double)))) return rc;
   if ((rc = ensure(c, c->cell_sums, (size_t)NE * n_slots * sizeof(double)))) return rc;
+  double* part_main = (double*)c->part.p;
+  double* part_rest = part_main + (size_t)segments * main_slots;
   CellmmArgs a;
   a.xd = (const float*)c->xs.p;
   a.tmeta = (const float*)c->cell_tmeta.p;
   a.img = (const unsigned char*)c->rec.p;
   a.scale = scale;
-  a.part = (double*)c->part.p;
-  a.n_slots = n_slots;
   a.m_stages = m_stages;
-  a.seg_stages = seg_stages;
-  a.segments = segments;
-  a.tile_blocks = (int)tile_blocks;
-  const dim3 grid_dim((unsigned)(tile_blocks * segments));
   if (NE == 1 && !sig_stale) HIP_TRY(c, mark(c, 0));  // resident signal: the timed region is the pair loop alone
   for (int col = 0; col < NE; ++col) {
     if (sig_stale) {  // the signal part of the image: max |b| -> sigma_b -> b sigma_b in tile order
@@ -1002,13 +1117,36 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
       HIP_TRY(c, hipGetLastError());
       if (NE == 1) HIP_TRY(c, mark(c, 0));
     }
-    hipError_t le = launch_cellmm_gaussian(TT, a, grid_dim, c->stream, &c->last_kernel_name);
+    hipError_t le = hipSuccess;
+    if (tile_blocks > 0) {
+      a.tile_base = 0;
+      a.tile_blocks = (int)tile_blocks;
+      a.part = part_main;
+      a.n_slots = main_slots;
+      a.seg_stages = seg_stages;
+      a.segments = segments;
+      le = launch_cellmm_gaussian(TT, a, dim3((unsigned)(tile_blocks * segments)), c->stream, &c->last_kernel_name);
+    }
+    if (le == hipSuccess && rest_blocks > 0) {  // the cells' leftover tiles, two per wavefront
+      a.tile_base = c->cell_n_main;
+      a.tile_blocks = (int)rest_blocks;
+      a.part = part_rest;
+      a.n_slots = rest_slots;
+      a.seg_stages = rest_seg_stages;
+      a.segments = rest_segments;
+      le = launch_cellmm_gaussian(2, a, dim3((unsigned)(rest_blocks * rest_segments)), c->stream, &c->last_kernel_name);
+    }
     if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2, 4 or 8");
     HIP_TRY(c, le);
     if (NE == 1) HIP_TRY(c, mark(c, 1));
-    // segments -> this column's sums in cell order
-    hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(n_slots)), dim3(256), 0, c->stream,
-                       (const double*)c->part.p, (double*)c->cell_sums.p + (size_t)col * n_slots, n_slots, segments);
+    // segments -> this column's sums in cell order (each launch's region with its own number of segments)
+    double* col_sums = (double*)c->cell_sums.p + (size_t)col * n_slots;
+    if (tile_blocks > 0)
+      hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(main_slots)), dim3(256), 0, c->stream,
+                         (const double*)part_main, col_sums, main_slots, segments);
+    if (rest_blocks > 0)
+      hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(rest_slots)), dim3(256), 0, c->stream,
+                         (const double*)part_rest, col_sums + main_slots, rest_slots, rest_segments);
     HIP_TRY(c, hipGetLastError());
   }
   if (NE > 1) HIP_TRY(c, mark(c, 1));  // several columns: the "kernel" time covers every column's pack + pair loop
