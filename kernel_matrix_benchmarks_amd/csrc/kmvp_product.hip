@@ -929,7 +929,7 @@ int run_product_cell(kmvp_ctx* c, int sig) {
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
   // the launch over the leftover tiles: its own, finer split of the sources and its own region of partial sums
-  int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, NE, n_slots, CELL_STAGE_BYTES, 1, small) : 0;
+  int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, NE, n_slots, CELL_STAGE_BYTES, 1, small, 2 << 20, 1536) : 0;
   const int64_t rest_seg_stages = rest_blocks > 0 ? (m_stages + rest_segments - 1) / rest_segments : 1;
   if (rest_blocks > 0) rest_segments = (int)((m_stages + rest_seg_stages - 1) / rest_seg_stages);
   const int64_t main_slots = c->cell_n_main * CELL_TILE, rest_slots = c->cell_n_rest * CELL_TILE;
@@ -1043,17 +1043,17 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   CellGrid grid;
   cell_load_grid(c, grid);
 
-  // segments of <= 3 MiB of source image (one per XCD at a time in its 4 MiB L2) and ~16 rounds of resident
+  // segments of <= 3 MiB of source image (one per XCD at a time in its 4 MiB L2) and ~14 rounds of resident
   // workgroups: 8 at the headline shape.  tools/cellmm_segments.py: 8 ... 32 segments run alike (28.3-28.5 ms),
   // 4 is slower (29.0); every segment costs n_slots x 8 bytes of partial sums written and read back and one more
   // pass over the targets, so the fewest that keep the chip full are taken (HBM-side traffic 0.44 -> 0.25 GB).
   int segments = choose_segments(c, std::max<int64_t>(1, tile_blocks), m_stages, 1, n_slots, CMM_STAGE_BYTES,
-                                 small ? 1 : 2, small, 3 << 20, 8192);
+                                 small ? 1 : 2, small, 3 << 20, 7168);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
   // the launch over the leftover tiles (two per wavefront, few workgroups) gets its own, finer split of the sources --
   // it is latency-bound per workgroup, so it needs many of them -- and its own region of partial sums
-  int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, 1, small, 3 << 20, 8192) : 0;
+  int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, 1, small, 3 << 20, 1536) : 0;
   const int64_t rest_seg_stages = rest_blocks > 0 ? (m_stages + rest_segments - 1) / rest_segments : 1;
   if (rest_blocks > 0) rest_segments = (int)((m_stages + rest_seg_stages - 1) / rest_seg_stages);
   const int64_t main_slots = c->cell_n_main * CELL_TILE, rest_slots = c->cell_n_rest * CELL_TILE;
