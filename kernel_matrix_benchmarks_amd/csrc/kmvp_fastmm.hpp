@@ -1,0 +1,261 @@
+// Gaussian products with SEVERAL signal columns (low-D attention with E value channels, bruteforce.py:142-153;
+// exp(<x,y>) attention through its Gaussian form): both matrix products of "K = exp(-sqdist); a = K @ b" on the
+// matrix cores, the kernel matrix never leaving the registers.
+//
+// fast_kernel (kmvp_fast.hpp) takes s = |x'|^2 + |y'|^2 - 2 x'.y' from split-bf16 MFMAs at fp32 accuracy and then
+// spends one VALU FMA per pair AND COLUMN on k(s) b_j: with E columns the difference form (lowd, blocks of four
+// columns) and the per-column cell forms all scale with E.  Here the tile of kernel values is handed back to the
+// matrix pipe:
+//
+//   S  (32 sources x 32 targets) = Y~ X~^T          KS bf16 MFMAs   (operands as in kmvp_fast.hpp, plus one column
+//                                                                    that subtracts FMM_SHIFT: T = 2^15 exp(-s))
+//   T  = exp2(-S)                                   16 v_exp_f32 per lane: the one transcendental per PAIR
+//   T  = T_h + T_l  (two f16: 11 + 11 bits)         v_cvt_pk_f16_f32, subtract, v_cvt_pk_f16_f32
+//   O (32 columns x 32 targets) += B'^T T           f16 MFMAs, fp32 accumulators: up to 32 signal columns at once
+//
+// The S tile comes out of the MFMA with the TARGET on the lane and 16 sources in the lane's registers, which IS the
+// B-operand layout of the second product (k = source) up to a permutation of k that the pre-packed signal operand
+// B' follows -- no cross-lane traffic between the two products.  fp32 accuracy needs the signal split as well,
+// b sigma_e = b_h + b_l (sigma_e a power of two per column, |b sigma_e| < 2^14):
+//   MODE 0 (<= 16 columns): the A operand holds b_h in rows 0..15 and b_l in rows 16..31 -> two MFMAs per 16 sources
+//          (with T_h and T_l), rows e and e + 16 added when the accumulator is folded;
+//   MODE 1 (<= 32 columns): A_h, A_l separately -> three MFMAs (A_h T_h, A_l T_h, A_h T_l).
+// Every FMM_CHUNK_TILES source tiles the fp32 accumulators are folded into fp64 registers (the chain of MFMA
+// accumulations stays short), and the partial sums leave as fp64 like everywhere else.
+//
+// Per 32 x 32 pairs and lane: 16 v_exp_f32 + ~40 full-rate instructions against 16 (1 + E) FMAs + 16 v_exp_f32,
+// and 2 + 4 (6) MFMAs of 8 passes beside them.  Error: T and b are carried to 2^-22, s as in fast_kernel
+// (eps32 (|x'|^2 + |y'|^2), clouds inside the radius rule) -- measured in tests/test_gpu_parity.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmvp_fast.hpp"
+
+namespace kmvp {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float fmm_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FMM_MAX_D = 8;
+#ifndef FMM_ST_MODE1
+#define FMM_ST_MODE1 2
+#endif
+__host__ __device__ constexpr int fmm_stage_tiles(int MODE) { return MODE ? FMM_ST_MODE1 : 4; }  // source tiles per LDS stage
+constexpr int FMM_SHIFT = 15;        // T = 2^15 exp(-s) <= 32768 < 65504: small kernel values stay normal f16 numbers
+constexpr int FMM_CHUNK_TILES = 32;  // source tiles per fp32 accumulation chain (default; FastmmArgs::chunk_stages)
+constexpr int FMM_MAX_COLS = 32;
+
+__host__ __device__ constexpr int fmm_ksteps(int D) { return (6 * D + 7 + 15) / 16; }
+__host__ __device__ constexpr int fmm_row_bytes(int KS) { return KS * 32 + 16; }
+__host__ __device__ constexpr int fmm_sig_bytes(int MODE) { return MODE ? 4096 : 2048; }
+__host__ __device__ constexpr int fmm_tile_bytes(int KS, int MODE) { return FAST_TILE * fmm_row_bytes(KS) + fmm_sig_bytes(MODE); }
+__host__ __device__ constexpr int fmm_stage_bytes(int KS, int MODE) {
+  return (fmm_stage_tiles(MODE) * fmm_tile_bytes(KS, MODE) + 4095) / 4096 * 4096;
+}
+
+struct FastmmArgs {
+  const float* xr;           // targets [n_pad][fast_target_row(D)] (pack_fast_targets_kernel)
+  const unsigned char* img;  // source stages [m_stages][fmm_stage_bytes]
+  const double* unscale;     // [32]: 2^-15 / sigma_e per column
+  double* part;              // partial sums [segments][NE][n_pad]
+  int64_t n_pad;
+  int64_t m_stages;
+  int64_t seg_stages;
+  int segments;
+  int tile_blocks;
+  int chunk_stages;
+  int NE;                    // columns written (numerators [+ denominator])
+};
+
+// element k of a target's augmented row: kmvp_fast.hpp's, plus -FMM_SHIFT against the source's 1 in column 6 D + 6
+template <int D, int K>
+__device__ __forceinline__ float fmm_target_elem(const float (&hi)[D + 1], const float (&mid)[D + 1],
+                                                 const float (&lo)[D + 1]) {
+  if constexpr (K == 6 * D + 6) return -(float)FMM_SHIFT;
+  else return fast_target_elem<D, K>(hi, mid, lo);
+}
+
+template <int D, int KS, int J>
+__device__ __forceinline__ void fmm_target_fill(bf16x8& out, int h, const float (&hi)[D + 1],
+                                                const float (&mid)[D + 1], const float (&lo)[D + 1]) {
+  if constexpr (J < 8) {
+    const float v0 = fmm_target_elem<D, KS * 16 + J>(hi, mid, lo);
+    const float v1 = fmm_target_elem<D, KS * 16 + 8 + J>(hi, mid, lo);
+    out[J] = (__bf16)(h ? v1 : v0);
+    fmm_target_fill<D, KS, J + 1>(out, h, hi, mid, lo);
+  }
+}
+
+template <int D, int KS>
+__device__ __forceinline__ void fmm_target_operand(bf16x8 (&xb)[fmm_ksteps(D)], int h, const float (&hi)[D + 1],
+                                                   const float (&mid)[D + 1], const float (&lo)[D + 1]) {
+  if constexpr (KS < fmm_ksteps(D)) {
+    fmm_target_fill<D, KS, 0>(xb[KS], h, hi, mid, lo);
+    fmm_target_operand<D, KS + 1>(xb, h, hi, mid, lo);
+  }
+}
+
+// t - (float)pair[0] and t - (float)pair[1] in ONE instruction each: v_fma_mix_f32 reads an f16 half of a register as
+// an fma operand (the compiler folds fma(h, -1, t) back into v_cvt_f32_f16 + v_sub_f32, a third more VALU work in the
+// pair loop)
+__device__ __forceinline__ float fmm_minus_lo_half(float t, h16x2 pair) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(t));
+  return r;
+}
+__device__ __forceinline__ float fmm_minus_hi_half(float t, h16x2 pair) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(t));
+  return r;
+}
+
+template <int D, int MODE, int TT>
+__global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs a) {
+  constexpr int KS = fmm_ksteps(D);
+  constexpr int RD = fast_target_row(D);
+  constexpr int RB = fmm_row_bytes(KS);
+  constexpr int TB = fmm_tile_bytes(KS, MODE);
+  constexpr int SB = fmm_stage_bytes(KS, MODE);
+  constexpr int PIECES = SB / (16 * BLOCK_THREADS);
+  constexpr int NOUT = MODE ? 16 : 8;  // output rows (columns of the result) per lane
+  static_assert(SB % (16 * BLOCK_THREADS) == 0, "stage = whole LDS-DMA pieces");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][SB];
+
+  int tb, seg;
+  block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
+
+  bf16x8 xb[TT][KS];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const float* row = a.xr + ((tile0 + tt) * FAST_TILE + r) * RD;
+    float v[RD];
+#pragma unroll
+    for (int q = 0; q < RD / 4; ++q) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(row + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * q + j] = w[j];
+    }
+    float hi[D + 1], mid[D + 1], lo[D + 1];
+#pragma unroll
+    for (int d = 0; d <= D; ++d) fast_split3f(v[d], hi[d], mid[d], lo[d]);
+    fmm_target_operand<D, 0>(xb[tt], h, hi, mid, lo);
+  }
+
+  f32x16 acc[TT];
+  double accd[TT][NOUT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) accd[tt][q] = 0.0;
+  }
+  // rows of the accumulator registers: register 4g + j holds row 8g + 4h + j.  MODE 0: rows e (g < 2) and e + 16
+  // (g + 2) are the two halves of column e; MODE 1: row = column.
+  auto fold = [&]() {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+      for (int q = 0; q < NOUT; ++q) {
+        if constexpr (MODE == 0) accd[tt][q] += (double)acc[tt][q] + (double)acc[tt][q + 8];
+        else accd[tt][q] += (double)acc[tt][q];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
+    }
+  };
+
+  const int64_t s_begin = (int64_t)seg * a.seg_stages;
+  int64_t s_end = s_begin + a.seg_stages;
+  if (s_end > a.m_stages) s_end = a.m_stages;
+
+  auto stage_in = [&](int64_t s, int buf) {
+    const unsigned char* src = a.img + s * SB;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+      const int piece = (p * WAVES_PER_BLOCK + wave) * 1024;  // wave-uniform LDS offset
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + piece + lane * 16),
+          (__attribute__((address_space(3))) void*)(&lds[buf][piece]), 16, 0, 0);
+    }
+  };
+  if (s_begin < s_end) stage_in(s_begin, 0);
+  __syncthreads();
+
+  int in_chunk = 0;
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    const int buf = (int)((s - s_begin) & 1);
+    if (s + 1 < s_end) stage_in(s + 1, buf ^ 1);
+#pragma unroll 1
+    for (int q = 0; q < fmm_stage_tiles(MODE); ++q) {
+      const unsigned char* lt = &lds[buf][q * TB];
+      bf16x8 ya[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        ya[ks] = *reinterpret_cast<const bf16x8*>(lt + r * RB + (ks * 16 + 8 * h) * 2);
+      // signal operands of the two k-steps of 16 sources: [k-step][lane] x 16 bytes (b_h | b_l rows in MODE 0)
+      const unsigned char* ls = lt + FAST_TILE * RB;
+      h16x8 ah[2], al[2];
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        ah[g2] = *reinterpret_cast<const h16x8*>(ls + g2 * 1024 + lane * 16);
+        if constexpr (MODE == 1) al[g2] = *reinterpret_cast<const h16x8*>(ls + 2048 + g2 * 1024 + lane * 16);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        f32x16 d;
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) d[qq] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[ks], xb[tt][ks], d, 0, 0, 0);
+        h16x8 th[2], tl[2];
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const fmm_f32x2 t = {kexp2(-d[8 * g2 + 2 * i]), kexp2(-d[8 * g2 + 2 * i + 1])};
+            const h16x2 hh = __builtin_convertvector(t, h16x2);
+            const fmm_f32x2 rest = {fmm_minus_lo_half(t[0], hh), fmm_minus_hi_half(t[1], hh)};
+            const h16x2 ll = __builtin_convertvector(rest, h16x2);
+            th[g2][2 * i] = hh[0];
+            th[g2][2 * i + 1] = hh[1];
+            tl[g2][2 * i] = ll[0];
+            tl[g2][2 * i + 1] = ll[1];
+          }
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g2], th[g2], acc[tt], 0, 0, 0);
+          if constexpr (MODE == 1) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g2], th[g2], acc[tt], 0, 0, 0);
+          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g2], tl[g2], acc[tt], 0, 0, 0);
+        }
+      }
+    }
+    if (++in_chunk == a.chunk_stages) {
+      in_chunk = 0;
+      fold();
+    }
+    __syncthreads();  // vmcnt(0) + barrier: stage s+1 has landed, stage s is free
+  }
+  fold();
+
+  // lane (r, h) holds target r of each tile and the columns e = 8g + 4h + j of its registers
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) {
+      const int e = 8 * (q >> 2) + 4 * h + (q & 3);
+      if (e < a.NE)
+        a.part[((int64_t)seg * a.NE + e) * a.n_pad + (tile0 + tt) * FAST_TILE + r] = accd[tt][q] * a.unscale[e];
+    }
+}
+
+}  // namespace kmvp

@@ -69,6 +69,14 @@ hipError_t launch_fast_invdist(int D, int sig, int TT, const FastArgs& args, dim
                                hipStream_t stream, const char** kernel_name);
 
 
+// both products on the matrix cores (kmvp_fastmm.hpp): Gaussian, float32, D <= 8, several signal columns
+// cost model of the auto choice between the two (ps per 32 x 32 tile of pairs, whole chip; tools/fmm_probe.py)
+constexpr double FMM_PS_PER_TILE_16 = 180.0, FMM_PS_PER_TILE_32 = 225.0;
+constexpr double CMM_PS_PER_TILE_MAIN = 26.0, CMM_PS_PER_TILE_REST = 48.0;
+struct FastmmArgs;
+hipError_t launch_fastmm_gaussian(int D, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
+                                  const char** kernel_name);
+
 // centred split-bf16 MFMA path (kmvp_cfast.hpp): D <= 4, E == 1, every kernel
 constexpr int CFAST_MAX_D = 4;
 constexpr int CFAST_DEFAULT_TT = 2;

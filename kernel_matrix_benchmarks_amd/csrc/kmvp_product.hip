@@ -9,6 +9,7 @@
 #include "kmvp_cellmm_pack.hpp"
 #include "kmvp_cfast_pack.hpp"
 #include "kmvp_fast_pack.hpp"
+#include "kmvp_fastmm_pack.hpp"
 #include "kmvp_mfma_pack.hpp"
 
 namespace kmvp {
@@ -567,6 +568,102 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
 
   // ---- epilogue: segments -> sums, [all-reduce over the source shards], normalise
   return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
+}
+
+// Gaussian products with several signal columns, both matrix products on the matrix cores (kmvp_fastmm.hpp): float32,
+// D <= 8, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
+int run_product_fastmm(kmvp_ctx* c, int sig) {
+  const int D = c->D, E = c->E;
+  const int NE = sig == SIG_NORM ? E + 1 : E;
+  const int64_t N = c->N, M = c->M;
+  const int KS = fmm_ksteps(D);
+  const int MODE = NE > 16 ? 1 : 0;
+  const bool small = N < SMALL_PROBLEM_TARGETS;
+  const int tt_max = MODE ? 2 : (D <= 4 ? 4 : 2);
+  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, tt_max) : (small ? 1 : 2);
+  const int64_t SB = fmm_stage_bytes(KS, MODE);
+  const float scale = scale_for<float>(K_GAUSSIAN);
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int64_t tile = (int64_t)FAST_TILE * TT * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(N, tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t m_tiles = (M + FAST_TILE - 1) / FAST_TILE;
+  const int64_t m_stages = (m_tiles + fmm_stage_tiles(MODE) - 1) / fmm_stage_tiles(MODE);
+  const int nb_max = std::min(NE, FMM_MAX_COLS);
+  int rc;
+
+  int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small);
+  const int64_t seg_stages = (m_stages + segments - 1) / segments;
+  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+  if (tile_blocks * segments > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
+
+  const int layout_T = TT + 16 * MODE;
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
+                         c->packed_layout != LAYOUT_FASTMM || c->packed_T != layout_T;
+  const bool one_block = NE <= FMM_MAX_COLS;
+  const bool sig_stale = pts_stale || !one_block || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  float* centre = (float*)c->aux.p;  // written by kmvp_set_points
+  if ((rc = ensure(c, c->cell_scale, 1024))) return rc;
+  float* sigma = (float*)((char*)c->cell_scale.p + 256);
+  double* unscale = (double*)((char*)c->cell_scale.p + 512);
+  if (pts_stale) {
+    const int RD = fast_target_row(D);
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * RD * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
+    hipLaunchKernelGGL(pack_fast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
+                       centre, (float*)c->xs.p, N, n_pad, D, RD, scale);
+    hipLaunchKernelGGL(pack_fastmm_rows_kernel, dim3(blocks_for(m_stages * fmm_stage_tiles(MODE) * FAST_TILE)), dim3(256), 0,
+                       c->stream, (const float*)c->y_raw.p, centre, (unsigned char*)c->rec.p, M, m_stages, D, KS, MODE,
+                       scale);
+    HIP_TRY(c, hipGetLastError());
+  }
+  c->packed_points_ver = c->points_ver;
+  c->packed_kernel = K_GAUSSIAN;
+  c->packed_layout = LAYOUT_FASTMM;
+  c->packed_T = layout_T;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_sig = one_block ? sig : -1;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * nb_max * n_pad * sizeof(double)))) return rc;
+  if (!one_block && (rc = ensure(c, c->sums, (size_t)NE * n_pad * sizeof(double)))) return rc;
+  FastmmArgs a;
+  a.xr = (const float*)c->xs.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.unscale = unscale;
+  a.part = (double*)c->part.p;
+  a.n_pad = n_pad;
+  a.m_stages = m_stages;
+  a.seg_stages = seg_stages;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.chunk_stages = std::max(1, 2 * c->opt_chunk / (FAST_TILE * fmm_stage_tiles(MODE)));
+  const dim3 grid((unsigned)(tile_blocks * segments));
+  const int64_t pieces = m_stages * fmm_stage_tiles(MODE) * (MODE ? 2 : 1) * 2 * 64;
+  HIP_TRY(c, mark(c, 0));
+  for (int col0 = 0; col0 < NE; col0 += FMM_MAX_COLS) {
+    const int nb = std::min(FMM_MAX_COLS, NE - col0);
+    if (sig_stale) {
+      hipLaunchKernelGGL(fastmm_colscale_kernel, dim3(FMM_MAX_COLS), dim3(256), 0, c->stream, (const float*)c->b_raw.p,
+                         M, E, col0, nb, sigma, unscale);
+      hipLaunchKernelGGL(pack_fastmm_signal_kernel, dim3(blocks_for(pieces)), dim3(256), 0, c->stream,
+                         (const float*)c->b_raw.p, (const float*)sigma, (unsigned char*)c->rec.p, M, m_stages, E, col0,
+                         nb, KS, MODE);
+      HIP_TRY(c, hipGetLastError());
+    }
+    a.NE = nb;
+    hipError_t le = launch_fastmm_gaussian(D, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
+    if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
+    HIP_TRY(c, le);
+    if (!one_block) {
+      const int Ek = std::min(nb, E - col0);  // signal columns of the block; the one beyond them is the denominator
+      hipLaunchKernelGGL(reduce_block_kernel, dim3(blocks_for((int64_t)nb * n_pad)), dim3(256), 0, c->stream,
+                         (const double*)c->part.p, (double*)c->sums.p, n_pad, nb, Ek, segments, col0, E);
+      HIP_TRY(c, hipGetLastError());
+    }
+  }
+  HIP_TRY(c, mark(c, 1));
+  if (one_block) return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
+  return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
 }
 
 // centred split-bf16 MFMA path (kmvp_cfast.hpp): float32, D <= 4, E == 1, every kernel.
@@ -1498,21 +1595,41 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   }
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
-  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && !c->density && c->E > 1 &&
-      c->centre_ver == c->points_ver && (c->opt_fast == 3 || c->opt_fast < 0)) {
-    // several signal columns (low-D attention with E value channels): one cellmm_kernel launch per column where the
-    // cell form applies (same rule as for E = 1 below)
+  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && !c->density && c->E > 1 && c->centre_ver == c->points_ver &&
+      (c->opt_fast < 0 || c->opt_fast == 1 || c->opt_fast == 3)) {
+    // Several signal columns (low-D attention with E value channels).  Two forms on the matrix cores:
+    //   fastmm_kernel  the tile of kernel values goes back to the matrix pipe for the product with the signal: up to 32
+    //                  columns per pass at a cost per pair that does not depend on the column count (D <= 8);
+    //   cellmm_kernel  one launch per column where the cell form applies (same rule as for E = 1 below; D <= 3) --
+    //                  a seventh of fastmm's cost per pair and column where the cells are well filled.
+    // auto takes the cheaper one by the tile counts (picoseconds per 32 x 32 tile on the whole chip, measured at
+    // 1e5 .. 1e6 points: tools/fmm_probe.py); fast_sqdists 1 / 3 force one of them.
     const float sc = scale_for<float>(kernel);
     const bool global_ok = c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2;
-    if (global_ok && (c->opt_fast == 3 || (c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
+    const int cols = c->E + (normalise ? 1 : 0);
+    const bool fmm_ok = c->D <= FMM_MAX_D && (c->opt_fast == 1 || (c->opt_fast < 0 && global_ok));
+    double t_cell = INFINITY;
+    if (c->D <= CELL_MAX_D && global_ok && c->opt_fast != 1 &&
+        (c->opt_fast == 3 || (c->N >= SMALL_PROBLEM_TARGETS && c->M >= SMALL_PROBLEM_TARGETS))) {
       const int TT = c->opt_fast_tiles > 0 ? c->opt_fast_tiles : (c->N < SMALL_PROBLEM_TARGETS ? 1 : 0);
       int rc = cell_prepare(c, TT);
       if (rc) return rc;
       if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD) &&
-          cellmm_wlog2(c) <= CMM_MAX_WLOG2) {
+          cellmm_wlog2(c) <= CMM_MAX_WLOG2)
+        t_cell = (double)cols * (double)c->cell_m_tiles *
+                 (CMM_PS_PER_TILE_MAIN * (double)c->cell_n_main + CMM_PS_PER_TILE_REST * (double)c->cell_n_rest);
+    }
+    if (fmm_ok) {
+      const double tiles = std::ceil((double)c->N / FAST_TILE) * std::ceil((double)c->M / FAST_TILE);
+      const double t_fmm = tiles * ((cols + FMM_MAX_COLS - 1) / FMM_MAX_COLS) * (cols > 16 ? FMM_PS_PER_TILE_32 : FMM_PS_PER_TILE_16);
+      if (c->opt_fast == 1 || t_fmm <= t_cell) {
         c->note.clear();
-        return run_product_cellmm(c, sig);
+        return run_product_fastmm(c, sig);
       }
+    }
+    if (t_cell < INFINITY) {
+      c->note.clear();
+      return run_product_cellmm(c, sig);
     }
   }
   if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && c->centre_ver == c->points_ver) note_no_cells(c);
