@@ -150,8 +150,11 @@ int kmvp_comm_rank(const kmvp_ctx* ctx);
  *   "segments"         number of source segments a launch is split into (0 = auto)
  *   "chunk"            sources summed in fp32 before folding into the fp64 sum
  *   "fast_sqdists"     squared distances in the expanded form |x|^2+|y|^2-2x.y on the matrix
- *                      cores (bruteforce.py:36-49 `fast_sqdists`; float32, D <= 39, E == 1):
- *                      1 = always, around one centre for the whole cloud (fast_kernel);
+ *                      cores (bruteforce.py:36-49 `fast_sqdists`; float32, D <= 39):
+ *                      1 = always, around one centre for the whole cloud: fast_kernel (E == 1); with several
+ *                          signal columns (Gaussian, D <= 8) fastmm_kernel, where the tile of kernel values goes
+ *                          back to the matrix cores for the product with the signal, up to 32 columns per pass
+ *                          (the denominator of normalised rows is one more column);
  *                      2 = always, around per-group centres of Morton-sorted sources with exact
  *                          recomputation of the closest pairs (cfast_kernel, D <= 4);
  *                      3 = always the cell form (Gaussian, D <= 3): exp() is range-reduced by the cells
@@ -167,7 +170,8 @@ int kmvp_comm_rank(const kmvp_ctx* ctx);
  *                      -1 = auto (default): the cheapest form that is as accurate as the
  *                          difference form -- for the Gaussian on clouds of small scaled radius
  *                          3 when both clouds fill the grid cells (>= 32768 points, padding
- *                          <= 30 %), else 1; else 2 where it applies
+ *                          <= 30 %), else 1 (several signal columns: 1 or 3, whichever costs less by
+ *                          the tile counts); else 2 where it applies
  *   "same_points_global" 1 when the targets passed to kmvp_set_points are the unsharded
  *                      sources (sharded same_points): enables form 2 for inverse-distance
  *   "partial_shard"    1: a source slice (M < M_total) may be run WITHOUT a multi-rank communicator and

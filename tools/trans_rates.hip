@@ -1,7 +1,8 @@
 // Micro-benchmark: issue cost (cycles per wave64 instruction on one SIMD) of the VALU
 // instructions the pair loops are made of, for 1, 2 and 4 resident waves per SIMD:
 // v_exp_f32, v_sqrt_f32, v_rsq_f32, v_rcp_f32, v_log_f32, v_fma_f32, v_pk_fma_f32,
-// v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_bf16_f32, v_ldexp_f32, v_fract_f32.
+// v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_bf16_f32, v_ldexp_f32, v_fract_f32, and the f16 conversions / v_fma_mix_f32 of
+// fastmm_kernel.
 // 16 independent registers per wave (issue behaviour, not latency).
 // Build: hipcc --offload-arch=gfx950 -O3 -o trans_rates trans_rates.hip
 #include <hip/hip_runtime.h>
@@ -23,6 +24,13 @@
 #define I_LDEXP(i) "v_ldexp_f32 %" #i ", %" #i ", 1\n\t"
 #define I_FRACT(i) "v_fract_f32 %" #i ", %" #i "\n\t"
 #define I_CVT(i) "v_cvt_pk_bf16_f32 %" #i ", %" #i ", %" #i "\n\t"
+#define I_CVTH(i) "v_cvt_pk_f16_f32 %" #i ", %" #i ", %" #i "\n\t"
+#define I_CVTZ(i) "v_cvt_pkrtz_f16_f32 %" #i ", %" #i ", %" #i "\n\t"
+#define I_MIX(i) "v_fma_mix_f32 %" #i ", %" #i ", -1.0, %" #i " op_sel_hi:[1,0,0]\n\t"
+#define I_AND(i) "v_and_b32 %" #i ", 0xffffe000, %" #i "\n\t"
+#define I_PERM(i) "v_perm_b32 %" #i ", %" #i ", %" #i ", %" #i "\n\t"
+#define I_SUB(i) "v_sub_f32 %" #i ", %" #i ", %" #i "\n\t"
+#define I_CVTF(i) "v_cvt_f32_f16 %" #i ", %" #i "\n\t"
 #define I_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %" #i ", %" #i "\n\t"
 #define I_PKADD(i) "v_pk_add_f32 %" #i ", %" #i ", %" #i "\n\t"
 #define I_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %" #i "\n\t"
@@ -47,6 +55,13 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
     if constexpr (MODE == 6) asm volatile(R16(I_LDEXP) OPS);
     if constexpr (MODE == 7) asm volatile(R16(I_FRACT) OPS);
     if constexpr (MODE == 8) asm volatile(R16(I_CVT) OPS);
+    if constexpr (MODE == 12) asm volatile(R16(I_CVTH) OPS);
+    if constexpr (MODE == 13) asm volatile(R16(I_CVTZ) OPS);
+    if constexpr (MODE == 14) asm volatile(R16(I_MIX) OPS);
+    if constexpr (MODE == 15) asm volatile(R16(I_AND) OPS);
+    if constexpr (MODE == 16) asm volatile(R16(I_PERM) OPS);
+    if constexpr (MODE == 17) asm volatile(R16(I_SUB) OPS);
+    if constexpr (MODE == 18) asm volatile(R16(I_CVTF) OPS);
     if constexpr (MODE == 9) asm volatile(P8(I_PKFMA) P8(I_PKFMA) POPS);
     if constexpr (MODE == 10) asm volatile(P8(I_PKADD) P8(I_PKADD) POPS);
     if constexpr (MODE == 11) asm volatile(P8(I_PKMUL) P8(I_PKMUL) POPS);
@@ -89,6 +104,13 @@ int main() {
     if (run<6>("v_ldexp_f32", w)) return 1;
     if (run<7>("v_fract_f32", w)) return 1;
     if (run<8>("v_cvt_pk_bf16_f32", w)) return 1;
+    if (run<12>("v_cvt_pk_f16_f32", w)) return 1;
+    if (run<13>("v_cvt_pkrtz_f16_f32", w)) return 1;
+    if (run<14>("v_fma_mix_f32", w)) return 1;
+    if (run<15>("v_and_b32", w)) return 1;
+    if (run<16>("v_perm_b32", w)) return 1;
+    if (run<17>("v_sub_f32", w)) return 1;
+    if (run<18>("v_cvt_f32_f16", w)) return 1;
     if (run<9>("v_pk_fma_f32", w)) return 1;
     if (run<10>("v_pk_add_f32", w)) return 1;
     if (run<11>("v_pk_mul_f32", w)) return 1;
