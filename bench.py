@@ -71,6 +71,11 @@ ROOF = {
     "fast_kernel": ("valu", 12.0, PEAK_FP32_VECTOR_TFLOPS, "SURVEY 8d's 12 flop per pair vs the fp32 vector peak"),
     "cfast_kernel": ("valu", 12.0, PEAK_FP32_VECTOR_TFLOPS, "SURVEY 8d's 12 flop per pair vs the fp32 vector peak"),
     "lowd_kernel": ("valu", 12.0, PEAK_FP32_VECTOR_TFLOPS, "SURVEY 8d's 3D + 2E + 1 = 12 flop per pair vs the fp32 vector peak"),
+    "fastmm_kernel": ("valu", 5.0, PEAK_FP32_VECTOR_TFLOPS,
+                      "5 VALU flop per pair, whatever the column count (v_exp_f32 = 1, v_cvt_pk_f16_f32 twice = 2, "
+                      "v_fma_mix_f32 = 2; both matrix products run on the MFMA pipe beside them) vs the fp32 vector peak; the "
+                      "three instructions cost 9.7 / 5.4 / 5.6 issue cycles per wave (profiles/r02_micro_trans_rates_f16.txt), "
+                      "i.e. 331 cycles per 32 x 32 tile: see issue_bound_frac"),
     "cell64_kernel": ("valu", 22.0, PEAK_FP64_VECTOR_TFLOPS,
                       "11 fp64 fma-class instructions per pair (3 for t = 2 d.e, 7 Horner steps of exp(t), 1 accumulate) "
                       "= 22 flop vs the fp64 vector peak 78.6 TFLOP/s"),
@@ -82,7 +87,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None, help="default: 10 (config 2, 3), 3 (4shard), 2 (4, 5)")
     p.add_argument("--warmup", type=int, default=None, help="default: 2 (config 2, 3), 1 otherwise")
-    p.add_argument("--config", choices=["2", "3", "4", "4shard", "5"], default="2")
+    p.add_argument("--config", choices=["2", "3", "4", "4shard", "5", "attn"], default="2",
+                   help="BASELINE config; attn (not a BASELINE config): D = 3 Gaussian attention with 16 value channels at "
+                        "N = M = 1e5, VERDICT r1 item 9")
     p.add_argument("--points", dest="n", type=float, default=None, help="override N = M of the config (not a BASELINE run)")
     p.add_argument("--kernel", choices=sorted(KERNELS), default=None, help="config 2 only: another kernel function")
     p.add_argument("--precision", choices=["float32", "float64"], default=None, help="config 2 only")
@@ -208,7 +215,7 @@ def main():
     if args.gpus > 1 and not distributed:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N")
-    if args.config in ("4shard", "5", "3") and args.gpus > 1:
+    if args.config in ("4shard", "5", "3", "attn") and args.gpus > 1:
         raise SystemExit(f"--config {args.config} is a single-GPU measurement")
 
     import numpy as np
@@ -243,8 +250,8 @@ def main():
             dist.barrier()
 
     cfg = args.config
-    steps = args.steps if args.steps is not None else {"2": 10, "3": 10, "4shard": 3, "4": 2, "5": 2}[cfg]
-    warmup = args.warmup if args.warmup is not None else {"2": 2, "3": 2}.get(cfg, 1)
+    steps = args.steps if args.steps is not None else {"2": 10, "3": 10, "4shard": 3, "4": 2, "5": 2, "attn": 10}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"2": 2, "3": 2, "attn": 2}.get(cfg, 1)
 
     # ---- the workload -------------------------------------------------------------------------------------
     D, E = 3, 1
@@ -258,6 +265,9 @@ def main():
     elif cfg == "3":
         kernel, precision, normalize = "absolute-exponential", "bfloat16", True
         n, D, E = int(args.n or 65536), 64, 64
+    elif cfg == "attn":
+        kernel, precision, normalize = "gaussian", "float32", True
+        n, E = int(args.n or 1e5), 16
     elif cfg in ("4", "4shard"):
         kernel, precision = "inverse-distance", "float32"
         n = int(args.n or 1e7)
@@ -458,9 +468,11 @@ def main():
             bound, fpp, peak, basis = ROOF.get(kname, ROOF["lowd_kernel"])
         achieved = fpp * shard_pairs / (k_ms * 1e-3) / 1e12
         tag = {"2": f"{'gaussian' if kernel == 'gaussian' else args.kernel}_1e6_{'f32' if precision == 'float32' else 'f64'}",
-               "3": "c3_absexp_bf16", "4": "c4_invdist_1e7_f32", "4shard": "c4shard_invdist_f32", "5": "c5_gaussian_1e5_f64"}[cfg]
+               "3": "c3_absexp_bf16", "4": "c4_invdist_1e7_f32", "4shard": "c4shard_invdist_f32", "5": "c5_gaussian_1e5_f64",
+               "attn": "attn_gaussian_1e5_e16_f32"}[cfg]
         traffic, traffic_source = (traffic_from_profile(kname, tag) if n == {"2": 1000000, "3": 65536, "4": 10000000,
-                                                                             "4shard": 10000000, "5": 100000}[cfg]
+                                                                             "4shard": 10000000, "5": 100000,
+                                                                             "attn": 100000}[cfg]
                                    and world == 1 else (None, None))
         esize = 8 if precision == "float64" else (2 if precision == "bfloat16" else 4)
         out = {
@@ -482,6 +494,8 @@ def main():
                          f"{precision}, same_points",
                     "3": f"BASELINE config 3: exp(-r) attention (row-normalised), uniform points / sqrt(D), N=M={n}, D={D}, "
                          f"E={E}, bf16 MFMA tiles, same_points",
+                    "attn": f"not a BASELINE config (VERDICT r1 item 9): Gaussian attention (row-normalised), uniform-3D, "
+                            f"N=M={n}, D=3, E={E} value channels, float32, same_points",
                     "4": f"BASELINE config 4: inverse-distance product, uniform-3D, N=M={n}, D=3, E=1, float32, sources "
                          f"sharded over {args.gpus} GPU(s)",
                     "4shard": f"BASELINE config 4, one of 8 source shards on one GPU: {n} targets x {my_sources} sources "
@@ -501,6 +515,9 @@ def main():
                                    "(reference fast_sqdists=True form)",
                     "cfast_kernel": "expanded around per-group centres of Morton-sorted sources on the bf16 matrix cores, "
                                     "closest pairs recomputed exactly",
+                    "fastmm_kernel": "expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, exp2 on the VALU, the tile of kernel "
+                                     "values split into two f16 pieces and multiplied with the (M, E [+1]) signal by a second "
+                                     "MFMA: up to 32 columns per pass",
                     "cell64_kernel": "float64 cells: exp() range-reduced by grid cells, degree-7 remainder on the fp64 VALU",
                 }.get(kname, "difference form (reference fast_sqdists=False)" if "lowd" in kname else kname),
             },
@@ -540,6 +557,11 @@ def main():
             r["survey_equivalent_note"] = ("SURVEY 8d prices a pair at 12 VALU flop; this kernel moved that work to the matrix "
                                            "pipe, so the figure may exceed the 157.3 TFLOP/s vector peak: it is an "
                                            "equivalent, not a fraction of any unit's peak")
+        if kname == "fastmm_kernel":
+            # VALU issue bound at the measured instruction costs, at the nominal 2.4 GHz
+            tiles32 = -(-n // 32) * -(-my_sources // 32) * (-(-(E + (1 if normalize else 0)) // 32))
+            r["issue_bound_ms"] = tiles32 * 331.0 / 1024 / 2.4e9 * 1e3
+            r["issue_bound_frac"] = r["issue_bound_ms"] / k_ms
         if kname == "cell_kernel":
             r["nonpacked_fp32_ceiling_tflops"] = NONPACKED_FP32_FMA_TFLOPS
             r["mfma_frac"] = 32.0 * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS

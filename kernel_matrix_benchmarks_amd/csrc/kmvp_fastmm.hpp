@@ -23,8 +23,8 @@
 // Every FMM_CHUNK_TILES source tiles the fp32 accumulators are folded into fp64 registers (the chain of MFMA
 // accumulations stays short), and the partial sums leave as fp64 like everywhere else.
 //
-// Per 32 x 32 pairs and lane: 16 v_exp_f32 + ~40 full-rate instructions against 16 (1 + E) FMAs + 16 v_exp_f32,
-// and 2 + 4 (6) MFMAs of 8 passes beside them.  Error: T and b are carried to 2^-22, s as in fast_kernel
+// Per 32 x 32 pairs and lane: 16 v_exp_f32 + 16 v_cvt_pk_f16_f32 + 16 v_fma_mix_f32 against 16 (1 + E) FMAs +
+// 16 v_exp_f32 of a VALU sum, and 2 + 4 (6) MFMAs of 8 passes beside them (331 issue cycles, measured 335).  Error: T and b are carried to 2^-22, s as in fast_kernel
 // (eps32 (|x'|^2 + |y'|^2), clouds inside the radius rule) -- measured in tests/test_gpu_parity.py.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -39,10 +39,7 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef float fmm_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FMM_MAX_D = 8;
-#ifndef FMM_ST_MODE1
-#define FMM_ST_MODE1 2
-#endif
-__host__ __device__ constexpr int fmm_stage_tiles(int MODE) { return MODE ? FMM_ST_MODE1 : 4; }  // source tiles per LDS stage
+__host__ __device__ constexpr int fmm_stage_tiles(int MODE) { return 4; }  // source tiles per LDS stage
 constexpr int FMM_SHIFT = 15;        // T = 2^15 exp(-s) <= 32768 < 65504: small kernel values stay normal f16 numbers
 constexpr int FMM_CHUNK_TILES = 32;  // source tiles per fp32 accumulation chain (default; FastmmArgs::chunk_stages)
 constexpr int FMM_MAX_COLS = 32;
@@ -193,13 +190,30 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
   for (int64_t s = s_begin; s < s_end; ++s) {
     const int buf = (int)((s - s_begin) & 1);
     if (s + 1 < s_end) stage_in(s + 1, buf ^ 1);
-#pragma unroll 1
-    for (int q = 0; q < fmm_stage_tiles(MODE); ++q) {
+    // The squared distances of tile q + 1 are issued before the kernel values of tile q are worked on: the matrix pipe
+    // runs them under the transcendentals and conversions of this very wave (the stage loop is unrolled, so the two
+    // register sets swap without copies).
+    constexpr int ST = fmm_stage_tiles(MODE);
+    f32x16 dn[TT];
+    auto distances = [&](int q, f32x16 (&d)[TT]) {
       const unsigned char* lt = &lds[buf][q * TB];
       bf16x8 ya[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         ya[ks] = *reinterpret_cast<const bf16x8*>(lt + r * RB + (ks * 16 + 8 * h) * 2);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) d[tt][qq] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          d[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[ks], xb[tt][ks], d[tt], 0, 0, 0);
+      }
+    };
+    distances(0, dn);
+#pragma unroll
+    for (int q = 0; q < ST; ++q) {
+      const unsigned char* lt = &lds[buf][q * TB];
       // signal operands of the two k-steps of 16 sources: [k-step][lane] x 16 bytes (b_h | b_l rows in MODE 0)
       const unsigned char* ls = lt + FAST_TILE * RB;
       h16x8 ah[2], al[2];
@@ -208,14 +222,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
         ah[g2] = *reinterpret_cast<const h16x8*>(ls + g2 * 1024 + lane * 16);
         if constexpr (MODE == 1) al[g2] = *reinterpret_cast<const h16x8*>(ls + 2048 + g2 * 1024 + lane * 16);
       }
+      f32x16 dc[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) dc[tt] = dn[tt];
+      if (q + 1 < ST) distances(q + 1, dn);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-        f32x16 d;
-#pragma unroll
-        for (int qq = 0; qq < 16; ++qq) d[qq] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[ks], xb[tt][ks], d, 0, 0, 0);
+        const f32x16 d = dc[tt];
         h16x8 th[2], tl[2];
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {

@@ -1,5 +1,5 @@
 // Instantiations of fastmm_kernel (kmvp_fastmm.hpp): D = point dimension, MODE = 0 (<= 16 columns) / 1 (<= 32),
-// TT = target tiles of 32 per wave.
+// TT = target tiles of 32 per wave (1 or 2).
 #include "kmvp_internal.hpp"
 #include "kmvp_fastmm.hpp"
 
@@ -10,12 +10,6 @@ static hipError_t launch_tt(int TT, const FastmmArgs& args, dim3 grid, hipStream
   switch (TT) {
     case 1: hipLaunchKernelGGL((fastmm_kernel<D, MODE, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
     case 2: hipLaunchKernelGGL((fastmm_kernel<D, MODE, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
-    case 4:
-      if constexpr (MODE == 0) {
-        hipLaunchKernelGGL((fastmm_kernel<D, MODE, 4>), grid, dim3(BLOCK_THREADS), 0, stream, args);
-        break;
-      }
-      return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -579,8 +579,7 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   const int KS = fmm_ksteps(D);
   const int MODE = NE > 16 ? 1 : 0;
   const bool small = N < SMALL_PROBLEM_TARGETS;
-  const int tt_max = MODE ? 2 : (D <= 4 ? 4 : 2);
-  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, tt_max) : (small ? 1 : 2);
+  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, 2) : (small ? 1 : 2);  // (four tiles: no faster, 256 VGPRs)
   const int64_t SB = fmm_stage_bytes(KS, MODE);
   const float scale = scale_for<float>(K_GAUSSIAN);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
@@ -592,7 +591,9 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   const int nb_max = std::min(NE, FMM_MAX_COLS);
   int rc;
 
-  int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small);
+  // (the kernel's time does not depend on the segment count between 8 and 48 at 1e5 points, the fp64 partial sums --
+  // segments x columns x N x 8 bytes -- and their reduction do: about 4096 workgroups instead of 16384)
+  int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small, 2 << 20, 4096);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
   if (tile_blocks * segments > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");

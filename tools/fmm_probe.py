@@ -17,10 +17,10 @@ def rel_err(got, want):
     return float(np.abs(got - want).max() / np.abs(want).max())
 
 
-def run(n, D, E, norm, form, tiles=0):
+def run(n, D, E, norm, form, tiles=0, segments=0):
     y, b = kmvp_oracle.uniform_cube(n, D, E=E)
     algo = MI355XProduct(kernel="gaussian", dimension=D, normalize_rows=norm, precision="float32", fast_sqdists=form,
-                         fast_tiles=tiles)
+                         fast_tiles=tiles, segments=segments)
     try:
         algo.prepare_data(source_points=y, target_points=y, same_points=True)
         algo.fit()
@@ -47,6 +47,11 @@ if __name__ == "__main__":
         for D, E, norm in shapes or ((3, 16, True), (3, 2, False), (3, 8, False), (3, 15, True), (3, 31, True), (3, 40, True), (2, 4, True), (5, 16, True), (8, 16, False)):
             forms = ((None, 0), (True, 2)) if os.environ.get("FMM_PROBE_SHORT") == "1" else ((True, 1), (True, 2), (True, 4)) if os.environ.get("FMM_PROBE_SHORT") == "2" else (
                 (None, 0), (True, 1), (True, 2), (True, 4), ("cells", 0), (False, 0))
+            if os.environ.get("FMM_PROBE_SEGMENTS"):
+                for seg in (int(v) for v in os.environ["FMM_PROBE_SEGMENTS"].split(",")):
+                    k, ms, err, colerr = run(n, D, E, norm, True, 2, seg)
+                    print(f"n={n} D={D} E={E} norm={int(norm)} segments={seg:3d} -> {k:14} {ms:9.3f} ms  err {err:.2e}", flush=True)
+                continue
             for form, tiles in forms:
                 if n > 200_000 and form is False:
                     continue
