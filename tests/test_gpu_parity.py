@@ -1528,3 +1528,19 @@ def test_rccl_binds_to_the_hip_runtime_in_use():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_stack_check.py")], cwd=root,
                          capture_output=True, text=True, timeout=600)
     assert "kmvp_first exit 0" in out.stdout and "torch_first exit 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py: 250 random combinations of kernel, D (1 .. 70), E (1 .. 65), N, M (1 .. 40000), same_points,
+    normalize_rows, density_estimation, precision and squared-distance form through the plugin, each against the float64
+    numpy oracle on the inputs as the working precision sees them (3000 more cases over other seeds were run by hand:
+    profiles/r02_fuzz_parity.txt)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    seen, failures = fuzz.sweep(250, 2024, verbose=False)
+    assert not failures, failures
+    assert {"lowd_kernel", "lowd_mid_kernel", "fast_kernel", "fastmm_kernel", "cfast_kernel"} <= set(seen), seen

@@ -1,0 +1,126 @@
+"""Randomised parity sweep: random shapes / kernels / query() branches / precisions / squared-distance forms through the
+plugin, every result against the float64 numpy oracle.  Prints one line per failure and a summary; exit code 1 on any.
+usage: python tools/fuzz_parity.py [cases=300] [seed=1]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct  # noqa: E402
+import kmvp_oracle  # noqa: E402  (checker only)
+
+KERNELS = ("gaussian", "absolute-exponential", "inverse-distance")
+FORMS = (None, None, False, True, "centred", "cells", "cells-valu")
+
+
+def one_case(rs):
+    kernel = KERNELS[rs.randint(3)]
+    D = int(rs.choice([1, 2, 3, 3, 3, 4, 5, 8, 9, 16, 40, 70]))
+    E = int(rs.choice([1, 1, 1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 65]))
+    N = int(rs.choice([1, 7, 31, 32, 33, 100, 257, 1000, 4097, 40000]))
+    M = int(rs.choice([1, 5, 31, 32, 33, 64, 127, 129, 1000, 3001, 40000]))
+    same = bool(rs.rand() < 0.3)
+    if same:
+        N = M
+    norm = bool(rs.rand() < 0.4)
+    dens = bool(rs.rand() < 0.15)
+    precision = ["float32", "float32", "float64", "float16"][rs.randint(4)]
+    form = FORMS[rs.randint(len(FORMS))]
+    tiles = int(rs.choice([0, 0, 1, 2, 4, 8]))
+    spread = float(rs.choice([0.3, 1.0, 1.0, 3.0]))
+    return dict(kernel=kernel, D=D, E=E, N=N, M=M, same=same, norm=norm, dens=dens, precision=precision, form=form,
+                tiles=tiles, spread=spread)
+
+
+def run_case(c, rs):
+    D, E, N, M = c["D"], c["E"], c["N"], c["M"]
+    y = rs.rand(M, D) * c["spread"] / np.sqrt(D / 3.0)
+    x = None if c["same"] else rs.rand(N, D) * c["spread"] / np.sqrt(D / 3.0)
+    b = None if c["dens"] else rs.randn(M, E)
+    if c["precision"] != "float64":
+        # the inputs as the working precision sees them (bruteforce.py:97-99 casts them first): the sweep checks the
+        # arithmetic, not what rounding a coordinate does to 1/r of nearly coincident points
+        wp = np.float16 if c["precision"] == "float16" else np.float32
+        y = y.astype(wp).astype(np.float64)
+        x = None if x is None else x.astype(wp).astype(np.float64)
+        b = None if b is None else b.astype(wp).astype(np.float64)
+    algo = MI355XProduct(kernel=c["kernel"], dimension=D, normalize_rows=c["norm"], precision=c["precision"],
+                         fast_sqdists=c["form"], fast_tiles=c["tiles"])
+    try:
+        algo.prepare_data(source_points=y, target_points=y if x is None else x, same_points=c["same"],
+                          density_estimation=c["dens"])
+        algo.fit()
+        algo.prepare_query(source_signal=b)
+        algo.query()
+        got = algo.get_result()
+        kname = algo.device_kernel
+    finally:
+        algo.done()
+    rows = None
+    if N * M > 20_000_000:  # the numpy oracle on a row sample
+        rows = np.sort(rs.choice(N, size=256, replace=False))
+        got = got[rows]
+    want = kmvp_oracle.product(kernel=c["kernel"], source_points=y, target_points=x, source_signal=b,
+                               normalize_rows=c["norm"], density_estimation=c["dens"], rows=rows)
+    finite = np.isfinite(want).all(axis=-1) if want.ndim > 1 else np.isfinite(want)
+    if got.shape != want.shape:
+        return kname, f"shape {got.shape} != {want.shape}"
+    gf = np.isfinite(got).all(axis=-1) if got.ndim > 1 else np.isfinite(got)
+    # fast_sqdists=True FORCED on exp(-r) or 1/r is the reference's expanded form with its absolute error in s
+    # (bruteforce.py:36-49: cancellation near s = 0; the reference's own float32 run takes sqrt of negative numbers there):
+    # loose tolerance, no claim on which rows overflow
+    forced_expanded = c["form"] is True and c["kernel"] != "gaussian" and kname == "fast_kernel"
+    if forced_expanded:
+        finite = finite & gf
+    if not np.array_equal(gf & finite, finite):
+        return kname, f"non-finite rows differ: {int(gf.sum())} vs {int(finite.sum())}"
+    if not finite.any():
+        return kname, None
+    scale = np.abs(want[finite]).max()
+    err = float(np.abs(got[finite] - want[finite]).max() / scale) if scale > 0 else float(np.abs(got[finite]).max())
+    tol = 1e-11 if c["precision"] == "float64" else 2e-5
+    if c["kernel"] == "inverse-distance" and c["precision"] != "float64":
+        tol = 2e-4  # 1/r of nearly coincident points
+    if forced_expanded:
+        tol = 5e-2 if c["kernel"] == "inverse-distance" else 2e-3
+    if err > tol and c["precision"] != "float64" and scale > 0:
+        # sums that cancel (|a| << sum |k b|) amplify every float32 rounding: the yardstick is then the reference's own
+        # float32 arithmetic on the same inputs, as in tests/test_gpu_parity.py (max(tolerance, 2 x its error))
+        ref32 = kmvp_oracle.product(kernel=c["kernel"], source_points=y, target_points=x, source_signal=b,
+                                    normalize_rows=c["norm"], density_estimation=c["dens"], rows=rows,
+                                    precision=np.float32)
+        ok32 = finite & (np.isfinite(ref32).all(axis=-1) if ref32.ndim > 1 else np.isfinite(ref32))
+        tol = max(tol, 2.0 * float(np.abs(ref32[ok32] - want[ok32]).max() / scale))
+    return kname, (None if err <= tol else f"error {err:.3e} > {tol:.0e}")
+
+
+def sweep(cases, seed, verbose=True):
+    rs = np.random.RandomState(seed)
+    seen, bad, failures = {}, 0, []
+    for i in range(cases):
+        c = one_case(rs)
+        try:
+            kname, msg = run_case(c, rs)
+        except NotImplementedError as exc:  # e.g. float16 with an unsupported combination: as the reference's ctor
+            kname, msg = "NotImplementedError", None
+        except Exception as exc:  # noqa: BLE001
+            kname, msg = "exception", f"{type(exc).__name__}: {exc}"
+        seen[kname] = seen.get(kname, 0) + 1
+        if msg:
+            bad += 1
+            failures.append(f"case {i} {c} -> {kname}: {msg}")
+            if verbose:
+                print("FAIL " + failures[-1], flush=True)
+        if verbose and (i + 1) % 50 == 0:
+            print(f"... {i + 1} cases, {bad} failures", flush=True)
+    return seen, failures
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seen, failures = sweep(n_cases, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n_cases} cases, {len(failures)} failures; kernels: {seen}")
+    sys.exit(1 if failures else 0)
