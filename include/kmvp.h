@@ -156,7 +156,9 @@ int kmvp_comm_rank(const kmvp_ctx* ctx);
  *                          back to the matrix cores for the product with the signal, up to 32 columns per pass
  *                          (the denominator of normalised rows is one more column);
  *                      2 = always, around per-group centres of Morton-sorted sources with exact
- *                          recomputation of the closest pairs (cfast_kernel, D <= 4);
+ *                          recomputation of the closest pairs (cfast_kernel, D <= 4; with several signal
+ *                          columns, Gaussian and exp(-r): cfastmm_kernel, the second product of fastmm_kernel
+ *                          on these distances);
  *                      3 = always the cell form (Gaussian, D <= 3): exp() is range-reduced by the cells
  *                          of a regular grid, exp(-|x-y|^2) = U_i(S) W_j(T) exp(2 d.e), and the remainder
  *                          polynomial 1 + t + t^2/2 of t = 2 d.e (|t| <= 0.016) comes out of one MFMA per

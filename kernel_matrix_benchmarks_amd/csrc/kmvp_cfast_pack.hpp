@@ -33,17 +33,15 @@ __global__ void cfast_morton_kernel(const float* __restrict__ y, const float* __
   keys[j] = key;
 }
 
-// One workgroup of CF_GROUP threads per group of sorted sources: centre = bounding-box midpoint of the
-// group in the caller's coordinates, rows y' = (y - c) * scale, tau = kappa * max |y'|^2, reach^2, signal,
-// the caller's fp32 coordinates, original global index.
-__global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
-    const float* __restrict__ y, const float* __restrict__ b, const int* __restrict__ perm,
-    unsigned char* __restrict__ img, int64_t m, int D, int EB, float scale, int64_t j_offset) {
-  const int64_t group = blockIdx.x;
+// The part of a group image the POINTS determine (shared by cfast_kernel's and cfastmm_kernel's images, which differ in
+// where the raw coordinates sit): one workgroup of CF_GROUP threads per group of sorted sources: centre = bounding-box
+// midpoint of the group in the caller's coordinates, rows y' = (y - c) * scale, tau = kappa * max |y'|^2, reach^2, the
+// caller's fp32 coordinates.  Returns the thread's source index (>= m: pad).
+__device__ __forceinline__ int cfast_pack_group_points(const float* __restrict__ y, const int* __restrict__ perm,
+                                                       unsigned char* __restrict__ g, int raw_off, int64_t group,
+                                                       int64_t m, int D, float scale) {
   const int rr = threadIdx.x;
   const int64_t k = group * CF_GROUP + rr;  // position in the sorted order
-  const int64_t stage = group / CF_STAGE_GROUPS;
-  unsigned char* g = img + stage * (int64_t)CF_STAGE_BYTES + (group % CF_STAGE_GROUPS) * CF_GROUP_BYTES;
   const int src = perm[k];  // pad positions carry indices >= m
   const bool live = src < m;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -121,9 +119,22 @@ __global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
   row[30] = zero;
   row[31] = zero;
   for (int q = 32; q < 40; ++q) row[q] = zero;
-  reinterpret_cast<float*>(g + CF_OFF_B)[rr] = (live && EB > 0) ? b[src] : 0.f;
-  float* raw = reinterpret_cast<float*>(g + CF_OFF_RAW) + rr * 4;
+  float* raw = reinterpret_cast<float*>(g + raw_off) + rr * 4;
   for (int d = 0; d < 4; ++d) raw[d] = live ? v[d] : INFINITY;
+  return src;
+}
+
+// cfast_kernel's group image: the points' part, the signal (one float per source), the original global index
+__global__ void __launch_bounds__(CF_GROUP) pack_cfast_sources_kernel(
+    const float* __restrict__ y, const float* __restrict__ b, const int* __restrict__ perm,
+    unsigned char* __restrict__ img, int64_t m, int D, int EB, float scale, int64_t j_offset) {
+  const int64_t group = blockIdx.x;
+  const int rr = threadIdx.x;
+  const int64_t stage = group / CF_STAGE_GROUPS;
+  unsigned char* g = img + stage * (int64_t)CF_STAGE_BYTES + (group % CF_STAGE_GROUPS) * CF_GROUP_BYTES;
+  const int src = cfast_pack_group_points(y, perm, g, CF_OFF_RAW, group, m, D, scale);
+  const bool live = src < m;
+  reinterpret_cast<float*>(g + CF_OFF_B)[rr] = (live && EB > 0) ? b[src] : 0.f;
   reinterpret_cast<int*>(g + CF_OFF_IDX)[rr] = live ? (int)(j_offset + src) : -1;
 }
 

@@ -22,7 +22,7 @@
 namespace kmvp {
 
 // which path's layouts the shared xs / rec buffers hold
-enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2, LAYOUT_CFAST = 3, LAYOUT_CELL = 4, LAYOUT_CELL64 = 5, LAYOUT_CELLMM = 6, LAYOUT_FASTMM = 7 };
+enum : int { LAYOUT_LOWD = 0, LAYOUT_FAST = 1, LAYOUT_MFMA = 2, LAYOUT_CFAST = 3, LAYOUT_CELL = 4, LAYOUT_CELL64 = 5, LAYOUT_CELLMM = 6, LAYOUT_FASTMM = 7, LAYOUT_CFASTMM = 8 };
 
 struct DevBuf {
   void* p = nullptr;

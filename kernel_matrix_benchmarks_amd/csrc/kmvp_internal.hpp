@@ -77,6 +77,12 @@ struct FastmmArgs;
 hipError_t launch_fastmm_gaussian(int D, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
                                   const char** kernel_name);
 
+// the same second product on cfast_kernel's distances (kmvp_cfastmm.hpp): Gaussian and exp(-r), float32, D <= 4
+struct CfastmmArgs;
+hipError_t launch_cfastmm(int kernel, int mode, int TT, const CfastmmArgs& args, dim3 grid, hipStream_t stream,
+                          const char** kernel_name);
+constexpr int CFMM_AUTO_MIN_COLS = 4;  // auto: from four columns on (1e5 points, four columns: 3.0 ms against 3.7 ms of the difference form)
+
 // centred split-bf16 MFMA path (kmvp_cfast.hpp): D <= 4, E == 1, every kernel
 constexpr int CFAST_MAX_D = 4;
 constexpr int CFAST_DEFAULT_TT = 2;

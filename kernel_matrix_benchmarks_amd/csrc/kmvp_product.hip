@@ -10,6 +10,7 @@
 #include "kmvp_cfast_pack.hpp"
 #include "kmvp_fast_pack.hpp"
 #include "kmvp_fastmm_pack.hpp"
+#include "kmvp_cfastmm_pack.hpp"
 #include "kmvp_mfma_pack.hpp"
 
 namespace kmvp {
@@ -667,6 +668,29 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
 }
 
+// Morton order of the sources (independent of the kernel; cfast_kernel and cfastmm_kernel): keys -> radix sort -> c->perm
+int morton_order(kmvp_ctx* c, int64_t m_alloc) {
+  int rc;
+  const float* centre = (const float*)c->aux.p;  // written by measure_clouds()
+  if (c->perm_ver == c->points_ver && c->perm.cap >= (size_t)m_alloc * sizeof(int)) return KMVP_OK;
+  if ((rc = ensure(c, c->perm, (size_t)m_alloc * sizeof(int)))) return rc;
+  size_t tmp_bytes = 0;
+  HIP_TRY(c, sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, m_alloc, c->stream));
+  const size_t keys_bytes = (size_t)m_alloc * sizeof(unsigned);
+  if ((rc = ensure(c, c->sortbuf, 3 * keys_bytes + tmp_bytes + 256))) return rc;
+  unsigned* keys_in = (unsigned*)c->sortbuf.p;
+  unsigned* keys_out = keys_in + m_alloc;
+  int* vals_in = (int*)(keys_out + m_alloc);
+  void* tmp = (void*)((((uintptr_t)(vals_in + m_alloc)) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(cfast_morton_kernel, dim3(blocks_for(m_alloc)), dim3(256), 0, c->stream,
+                     (const float*)c->y_raw.p, centre, keys_in, vals_in, c->M, m_alloc, c->D);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, sort_pairs_u32(tmp, &tmp_bytes, keys_in, keys_out, vals_in, (int*)c->perm.p, m_alloc, c->stream));
+  c->perm_ver = c->points_ver;
+  c->packed_layout = -1;  // force a re-pack
+  return KMVP_OK;
+}
+
 // centred split-bf16 MFMA path (kmvp_cfast.hpp): float32, D <= 4, E == 1, every kernel.
 int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   const int D = c->D;
@@ -691,25 +715,7 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
   segments = (int)((m_stages + seg_stages - 1) / seg_stages);
 
-  const float* centre = (const float*)c->aux.p;  // written by measure_clouds()
-  if (c->perm_ver != c->points_ver) {
-    // Morton order of the sources (independent of the kernel): keys -> radix sort -> perm
-    if ((rc = ensure(c, c->perm, (size_t)m_alloc * sizeof(int)))) return rc;
-    size_t tmp_bytes = 0;
-    HIP_TRY(c, sort_pairs_u32(nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, m_alloc, c->stream));
-    const size_t keys_bytes = (size_t)m_alloc * sizeof(unsigned);
-    if ((rc = ensure(c, c->sortbuf, 3 * keys_bytes + tmp_bytes + 256))) return rc;
-    unsigned* keys_in = (unsigned*)c->sortbuf.p;
-    unsigned* keys_out = keys_in + m_alloc;
-    int* vals_in = (int*)(keys_out + m_alloc);
-    void* tmp = (void*)((((uintptr_t)(vals_in + m_alloc)) + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(cfast_morton_kernel, dim3(blocks_for(m_alloc)), dim3(256), 0, c->stream,
-                       (const float*)c->y_raw.p, centre, keys_in, vals_in, M, m_alloc, D);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, sort_pairs_u32(tmp, &tmp_bytes, keys_in, keys_out, vals_in, (int*)c->perm.p, m_alloc, c->stream));
-    c->perm_ver = c->points_ver;
-    c->packed_layout = -1;  // force a re-pack below
-  }
+  if ((rc = morton_order(c, m_alloc))) return rc;
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
                          c->packed_layout != LAYOUT_CFAST || c->packed_T != TT;
   const bool sig_stale = pts_stale || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
@@ -763,6 +769,100 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
 }
 
 // ---- cell-reduced Gaussian path (kmvp_cell.hpp): float32, D <= 3, E == 1 -----------------------------
+
+// Several signal columns on cfast_kernel's distances (kmvp_cfastmm.hpp): exp(-r), and the Gaussian outside the radius
+// rule; float32, D <= 4, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
+int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
+  const int D = c->D, E = c->E;
+  const int NE = sig == SIG_NORM ? E + 1 : E;
+  const int64_t N = c->N, M = c->M;
+  const int MODE = NE > 16 ? 1 : 0;
+  const bool small = N < SMALL_PROBLEM_TARGETS;
+  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, 2) : (small ? 1 : 2);
+  const int64_t SB = cfm_stage_bytes(MODE);
+  const float scale = scale_for<float>(kernel);
+  const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
+  const int64_t tile = (int64_t)32 * TT * WAVES_PER_BLOCK;
+  const int64_t n_pad = round_up(N, tile);
+  const int64_t tile_blocks = n_pad / tile;
+  const int64_t m_stages = (M + CF_GROUP - 1) / CF_GROUP;  // one group per stage
+  const int64_t m_alloc = m_stages * CF_GROUP;
+  const int nb_max = std::min(NE, FMM_MAX_COLS);
+  if (c->m_total > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "more than 2^31 sources");
+  int rc;
+
+  int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small, 2 << 20, 4096);
+  const int64_t seg_stages = (m_stages + segments - 1) / segments;
+  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
+  if (tile_blocks * segments > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
+
+  if ((rc = morton_order(c, m_alloc))) return rc;
+  const int layout_T = TT + 16 * MODE;
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+                         c->packed_layout != LAYOUT_CFASTMM || c->packed_T != layout_T;
+  const bool one_block = NE <= FMM_MAX_COLS;
+  const bool sig_stale = pts_stale || !one_block || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
+  if ((rc = ensure(c, c->cell_scale, 1024))) return rc;
+  float* sigma = (float*)((char*)c->cell_scale.p + 256);
+  double* unscale = (double*)((char*)c->cell_scale.p + 512);
+  if (pts_stale) {
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * 4 * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
+    hipLaunchKernelGGL(pack_cfast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
+                       (float*)c->xs.p, N, n_pad, D);
+    hipLaunchKernelGGL(pack_cfastmm_points_kernel, dim3((unsigned)m_stages), dim3(CF_GROUP), 0, c->stream,
+                       (const float*)c->y_raw.p, (const int*)c->perm.p, (unsigned char*)c->rec.p, M, D, MODE, scale);
+    HIP_TRY(c, hipGetLastError());
+  }
+  c->packed_points_ver = c->points_ver;
+  c->packed_kernel = kernel;
+  c->packed_layout = LAYOUT_CFASTMM;
+  c->packed_T = layout_T;
+  c->packed_signal_ver = c->signal_ver;
+  c->packed_sig = one_block ? sig : -1;
+
+  if ((rc = ensure(c, c->part, (size_t)segments * nb_max * n_pad * sizeof(double)))) return rc;
+  if (!one_block && (rc = ensure(c, c->sums, (size_t)NE * n_pad * sizeof(double)))) return rc;
+  CfastmmArgs a;
+  a.xraw = (const float*)c->xs.p;
+  a.img = (const unsigned char*)c->rec.p;
+  a.unscale = unscale;
+  a.part = (double*)c->part.p;
+  a.n_pad = n_pad;
+  a.m_stages = m_stages;
+  a.seg_stages = seg_stages;
+  a.segments = segments;
+  a.tile_blocks = (int)tile_blocks;
+  a.chunk_stages = std::max(1, 2 * c->opt_chunk / CF_GROUP);
+  a.scale = scale;
+  const dim3 grid((unsigned)(tile_blocks * segments));
+  const int64_t pieces = m_stages * (CF_GROUP / 32) * (MODE ? 2 : 1) * 2 * 64;
+  HIP_TRY(c, mark(c, 0));
+  for (int col0 = 0; col0 < NE; col0 += FMM_MAX_COLS) {
+    const int nb = std::min(FMM_MAX_COLS, NE - col0);
+    if (sig_stale) {
+      hipLaunchKernelGGL(fastmm_colscale_kernel, dim3(FMM_MAX_COLS), dim3(256), 0, c->stream, (const float*)c->b_raw.p,
+                         M, E, col0, nb, sigma, unscale);
+      hipLaunchKernelGGL(pack_cfastmm_signal_kernel, dim3(blocks_for(pieces)), dim3(256), 0, c->stream,
+                         (const float*)c->b_raw.p, (const float*)sigma, (const int*)c->perm.p, (unsigned char*)c->rec.p,
+                         M, m_stages, E, col0, nb, MODE);
+      HIP_TRY(c, hipGetLastError());
+    }
+    a.NE = nb;
+    hipError_t le = launch_cfastmm(kernel, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
+    if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "no cfastmm_kernel for this kernel / tile count");
+    HIP_TRY(c, le);
+    if (!one_block) {
+      const int Ek = std::max(0, std::min(nb, E - col0));
+      hipLaunchKernelGGL(reduce_block_kernel, dim3(blocks_for((int64_t)nb * n_pad)), dim3(256), 0, c->stream,
+                         (const double*)c->part.p, (double*)c->sums.p, n_pad, nb, Ek, segments, col0, E);
+      HIP_TRY(c, hipGetLastError());
+    }
+  }
+  HIP_TRY(c, mark(c, 1));
+  if (one_block) return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
+  return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
+}
 
 // Cell order of one cloud: keys -> radix sort; the sorted keys come back to the host, where the
 // tile lists are built (one pass over n keys, once per kmvp_set_points).
@@ -1632,6 +1732,14 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       c->note.clear();
       return run_product_cellmm(c, sig);
     }
+  }
+  if (c->dtype == KMVP_F32 && (kernel == K_GAUSSIAN || kernel == K_ABSEXP) && !c->density && c->E > 1 &&
+      c->D <= CFAST_MAX_D && c->centre_ver == c->points_ver &&
+      (c->opt_fast == 2 || (c->opt_fast < 0 && c->E + (normalise ? 1 : 0) >= CFMM_AUTO_MIN_COLS))) {
+    // several signal columns where fastmm_kernel does not apply: exp(-r), which needs relative accuracy in s, and the
+    // Gaussian on clouds outside the radius rule -- cfast_kernel's distances, the same second product
+    c->note.clear();
+    return run_product_cfastmm(c, kernel, sig);
   }
   if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && c->D <= CELL_MAX_D && c->centre_ver == c->points_ver) note_no_cells(c);
   if (c->dtype == KMVP_F32 && c->D <= FAST_MAX_D && (c->density || c->E == 1) && c->centre_ver == c->points_ver) {

@@ -318,6 +318,59 @@ def test_fastmm_kernel_column_blocks_and_ragged_sizes(D, E, norm):
     assert np.array_equal(got2, 2.0 * got)  # powers of two go through the column scales exactly
 
 
+CFMM_MULTI = [c for c in CASES if c["D"] <= 4 and c["kernel"] in ("gaussian", "absolute-exponential") and c["E"] > 1
+              and not c["density_estimation"]]
+
+
+@pytest.mark.parametrize("case", CFMM_MULTI, ids=[c["name"] for c in CFMM_MULTI])
+def test_cfastmm_kernel_with_several_signal_columns_matches_reference(case, expected):
+    """E > 1, fast_sqdists="centred": cfast_kernel's distances (group centres, exact near pairs) feeding the second
+    matrix product of fastmm_kernel (kmvp_cfastmm.hpp) -- exp(-r) and the Gaussian, D <= 4."""
+    y, x, b = golden_cases.make_inputs(case)
+    truth = expected[f"{case['name']}/f64"]
+    ref32 = expected[f"{case['name']}/f32"].astype(np.float64)
+    results = []
+    for tiles in (1, 2):
+        got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists="centred", fast_tiles=tiles)
+        assert extra["device_kernel"] == "cfastmm_kernel", extra
+        tol = max(TOL32, 2 * rel_err(ref32, truth))
+        assert got.shape == truth.shape and rel_err(got, truth) <= tol, (tiles, rel_err(got, truth), tol)
+        results.append(got)
+    assert np.array_equal(results[0], results[1])
+
+
+@pytest.mark.parametrize("kernel,D,E,norm", [("absolute-exponential", 3, 40, True), ("absolute-exponential", 1, 5, False),
+                                             ("absolute-exponential", 4, 33, False), ("gaussian", 2, 17, True)])
+def test_cfastmm_kernel_near_pairs_column_blocks_and_wide_clouds(kernel, D, E, norm):
+    """Clustered clouds far from the origin and wider than fast_kernel's radius rule, with exact and near duplicates
+    between targets and sources (the exact branch of the group search must fire: exp(-r) has a kink at r = 0), ragged N
+    and M, more than 32 columns; auto picks cfastmm_kernel here.  Against the float64 oracle on the float32-rounded
+    inputs."""
+    rng = np.random.RandomState(7 * D + E)
+    n, m = 1531, 2777
+    centres = rng.rand(12, D) * 9.0 + 100.0
+    y = (centres[rng.randint(12, size=m)] + 0.05 * rng.randn(m, D)).astype(np.float32).astype(np.float64)
+    x = (centres[rng.randint(12, size=n)] + 0.05 * rng.randn(n, D)).astype(np.float32).astype(np.float64)
+    x[:200] = y[:200]                                                   # coincident pairs
+    x[200:400] = (y[200:400] + 1e-5).astype(np.float32).astype(np.float64)  # pairs a few float32 ulps apart
+    b = rng.randn(m, E).astype(np.float32).astype(np.float64)
+    algo = MI355XProduct(kernel=kernel, dimension=D, normalize_rows=norm, precision="float32")
+    try:
+        algo.prepare_data(source_points=y, target_points=x)
+        algo.fit()
+        algo.prepare_query(source_signal=b)
+        algo.query()
+        got = algo.get_result()
+        assert algo.device_kernel == "cfastmm_kernel", algo.device_kernel
+    finally:
+        algo.done()
+    want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b, normalize_rows=norm)
+    ref32 = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b, normalize_rows=norm,
+                                precision=np.float32)
+    assert got.shape == (n, E)
+    assert rel_err(got, want) <= max(TOL32, 2 * rel_err(ref32, want)), (rel_err(got, want), rel_err(ref32, want))
+
+
 def test_auto_choice_between_fastmm_and_cellmm():
     """auto takes the cheaper of the two matrix-core forms by the tile counts: at 1e5 uniform points two columns are
     cheaper as two cellmm_kernel launches, nine as one fastmm_kernel pass."""
@@ -1543,4 +1596,4 @@ def test_randomised_parity_sweep():
     spec.loader.exec_module(fuzz)
     seen, failures = fuzz.sweep(250, 2024, verbose=False)
     assert not failures, failures
-    assert {"lowd_kernel", "lowd_mid_kernel", "fast_kernel", "fastmm_kernel", "cfast_kernel"} <= set(seen), seen
+    assert {"lowd_kernel", "lowd_mid_kernel", "fast_kernel", "fastmm_kernel", "cfast_kernel", "cfastmm_kernel"} <= set(seen), seen

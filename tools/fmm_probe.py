@@ -17,9 +17,14 @@ def rel_err(got, want):
     return float(np.abs(got - want).max() / np.abs(want).max())
 
 
+KERNEL = os.environ.get("FMM_PROBE_KERNEL", "gaussian")
+SPREAD = float(os.environ.get("FMM_PROBE_SPREAD", "1"))  # > 1: clouds outside fast_kernel's radius rule
+
+
 def run(n, D, E, norm, form, tiles=0, segments=0):
     y, b = kmvp_oracle.uniform_cube(n, D, E=E)
-    algo = MI355XProduct(kernel="gaussian", dimension=D, normalize_rows=norm, precision="float32", fast_sqdists=form,
+    y = y * SPREAD
+    algo = MI355XProduct(kernel=KERNEL, dimension=D, normalize_rows=norm, precision="float32", fast_sqdists=form,
                          fast_tiles=tiles, segments=segments)
     try:
         algo.prepare_data(source_points=y, target_points=y, same_points=True)
@@ -35,7 +40,7 @@ def run(n, D, E, norm, form, tiles=0, segments=0):
     finally:
         algo.done()
     rows = np.random.RandomState(8).choice(n, size=min(n, 128), replace=False)
-    want = c_oracle.product(kernel="gaussian", source_points=y, source_signal=b, rows=rows, normalize_rows=norm)
+    want = c_oracle.product(kernel=KERNEL, source_points=y, source_signal=b, rows=rows, normalize_rows=norm)
     return kname, best, rel_err(got[rows], want), float(np.abs((got[rows] - want) / np.abs(want).max(axis=0)).max())
 
 
@@ -45,7 +50,7 @@ if __name__ == "__main__":
         shapes = os.environ.get("FMM_PROBE_SHAPES")
         shapes = [tuple(int(v) for v in sh.split(",")) for sh in shapes.split(";")] if shapes else None
         for D, E, norm in shapes or ((3, 16, True), (3, 2, False), (3, 8, False), (3, 15, True), (3, 31, True), (3, 40, True), (2, 4, True), (5, 16, True), (8, 16, False)):
-            forms = ((None, 0), (True, 2)) if os.environ.get("FMM_PROBE_SHORT") == "1" else ((True, 1), (True, 2), (True, 4)) if os.environ.get("FMM_PROBE_SHORT") == "2" else (
+            forms = ((None, 0), (True, 2)) if os.environ.get("FMM_PROBE_SHORT") == "1" else ((True, 1), (True, 2), (True, 4)) if os.environ.get("FMM_PROBE_SHORT") == "2" else ((None, 0), ("centred", 1), ("centred", 2), (False, 0)) if os.environ.get("FMM_PROBE_SHORT") == "3" else (
                 (None, 0), (True, 1), (True, 2), (True, 4), ("cells", 0), (False, 0))
             if os.environ.get("FMM_PROBE_SEGMENTS"):
                 for seg in (int(v) for v in os.environ["FMM_PROBE_SEGMENTS"].split(",")):

@@ -31,6 +31,9 @@
 #define I_PERM(i) "v_perm_b32 %" #i ", %" #i ", %" #i ", %" #i "\n\t"
 #define I_SUB(i) "v_sub_f32 %" #i ", %" #i ", %" #i "\n\t"
 #define I_CVTF(i) "v_cvt_f32_f16 %" #i ", %" #i "\n\t"
+#define I_EXPH(i) "v_exp_f16 %" #i ", %" #i "\n\t"
+#define I_SQRTH(i) "v_sqrt_f16 %" #i ", %" #i "\n\t"
+#define I_EXPL(i) "v_exp_legacy_f32 %" #i ", %" #i "\n\t"
 #define I_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %" #i ", %" #i "\n\t"
 #define I_PKADD(i) "v_pk_add_f32 %" #i ", %" #i ", %" #i "\n\t"
 #define I_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %" #i "\n\t"
@@ -62,6 +65,9 @@ __global__ void __launch_bounds__(256) k(float* out, int iters) {
     if constexpr (MODE == 16) asm volatile(R16(I_PERM) OPS);
     if constexpr (MODE == 17) asm volatile(R16(I_SUB) OPS);
     if constexpr (MODE == 18) asm volatile(R16(I_CVTF) OPS);
+    if constexpr (MODE == 19) asm volatile(R16(I_EXPH) OPS);
+    if constexpr (MODE == 20) asm volatile(R16(I_SQRTH) OPS);
+    if constexpr (MODE == 21) asm volatile(R16(I_EXPL) OPS);
     if constexpr (MODE == 9) asm volatile(P8(I_PKFMA) P8(I_PKFMA) POPS);
     if constexpr (MODE == 10) asm volatile(P8(I_PKADD) P8(I_PKADD) POPS);
     if constexpr (MODE == 11) asm volatile(P8(I_PKMUL) P8(I_PKMUL) POPS);
@@ -111,6 +117,9 @@ int main() {
     if (run<16>("v_perm_b32", w)) return 1;
     if (run<17>("v_sub_f32", w)) return 1;
     if (run<18>("v_cvt_f32_f16", w)) return 1;
+    if (run<19>("v_exp_f16", w)) return 1;
+    if (run<20>("v_sqrt_f16", w)) return 1;
+    if (run<21>("v_exp_legacy_f32", w)) return 1;
     if (run<9>("v_pk_fma_f32", w)) return 1;
     if (run<10>("v_pk_add_f32", w)) return 1;
     if (run<11>("v_pk_mul_f32", w)) return 1;
