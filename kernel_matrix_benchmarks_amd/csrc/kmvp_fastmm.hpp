@@ -8,7 +8,8 @@
 // matrix pipe:
 //
 //   S  (32 sources x 32 targets) = Y~ X~^T          KS bf16 MFMAs   (operands as in kmvp_fast.hpp, plus one column
-//                                                                    that subtracts FMM_SHIFT: T = 2^15 exp(-s))
+//                                                                    that subtracts FMM_SHIFT: T = 2^15 exp(-s));
+//                                                                    D <= 39, KS = ceil((6 D + 7) / 16) <= 16
 //   T  = exp2(-S)                                   16 v_exp_f32 per lane: the one transcendental per PAIR
 //   T  = T_h + T_l  (two f16: 11 + 11 bits)         v_cvt_pk_f16_f32, subtract, v_cvt_pk_f16_f32
 //   O (32 columns x 32 targets) += B'^T T           f16 MFMAs, fp32 accumulators: up to 32 signal columns at once
@@ -38,8 +39,11 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef float fmm_f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int FMM_MAX_D = 8;
-__host__ __device__ constexpr int fmm_stage_tiles(int MODE) { return 4; }  // source tiles per LDS stage
+constexpr int FMM_MAX_D = 39;  // K = 6 D + 7 <= 241: 16 k-steps of 16 (fast_kernel's range)
+constexpr int FMM_MAX_KS = 16;
+constexpr int FMM_MAX_KS_TWO_TILES = 4;  // two target tiles per wave while the operands are small (D <= 9)
+// source tiles per LDS stage: four while a stage stays below ~30 KiB, two up to K = 144, one beyond
+__host__ __device__ constexpr int fmm_stage_tiles(int KS) { return KS <= 4 ? 4 : (KS <= 9 ? 2 : 1); }
 constexpr int FMM_SHIFT = 15;        // T = 2^15 exp(-s) <= 32768 < 65504: small kernel values stay normal f16 numbers
 constexpr int FMM_CHUNK_TILES = 32;  // source tiles per fp32 accumulation chain (default; FastmmArgs::chunk_stages)
 constexpr int FMM_MAX_COLS = 32;
@@ -49,11 +53,11 @@ __host__ __device__ constexpr int fmm_row_bytes(int KS) { return KS * 32 + 16; }
 __host__ __device__ constexpr int fmm_sig_bytes(int MODE) { return MODE ? 4096 : 2048; }
 __host__ __device__ constexpr int fmm_tile_bytes(int KS, int MODE) { return FAST_TILE * fmm_row_bytes(KS) + fmm_sig_bytes(MODE); }
 __host__ __device__ constexpr int fmm_stage_bytes(int KS, int MODE) {
-  return (fmm_stage_tiles(MODE) * fmm_tile_bytes(KS, MODE) + 4095) / 4096 * 4096;
+  return (fmm_stage_tiles(KS) * fmm_tile_bytes(KS, MODE) + 4095) / 4096 * 4096;
 }
 
 struct FastmmArgs {
-  const float* xr;           // targets [n_pad][fast_target_row(D)] (pack_fast_targets_kernel)
+  const unsigned char* xop;  // target operands [n_pad / 32][KS][64 lanes] x 16 bytes (pack_fastmm_targets_kernel)
   const unsigned char* img;  // source stages [m_stages][fmm_stage_bytes]
   const double* unscale;     // [32]: 2^-15 / sigma_e per column
   double* part;              // partial sums [segments][NE][n_pad]
@@ -65,34 +69,6 @@ struct FastmmArgs {
   int chunk_stages;
   int NE;                    // columns written (numerators [+ denominator])
 };
-
-// element k of a target's augmented row: kmvp_fast.hpp's, plus -FMM_SHIFT against the source's 1 in column 6 D + 6
-template <int D, int K>
-__device__ __forceinline__ float fmm_target_elem(const float (&hi)[D + 1], const float (&mid)[D + 1],
-                                                 const float (&lo)[D + 1]) {
-  if constexpr (K == 6 * D + 6) return -(float)FMM_SHIFT;
-  else return fast_target_elem<D, K>(hi, mid, lo);
-}
-
-template <int D, int KS, int J>
-__device__ __forceinline__ void fmm_target_fill(bf16x8& out, int h, const float (&hi)[D + 1],
-                                                const float (&mid)[D + 1], const float (&lo)[D + 1]) {
-  if constexpr (J < 8) {
-    const float v0 = fmm_target_elem<D, KS * 16 + J>(hi, mid, lo);
-    const float v1 = fmm_target_elem<D, KS * 16 + 8 + J>(hi, mid, lo);
-    out[J] = (__bf16)(h ? v1 : v0);
-    fmm_target_fill<D, KS, J + 1>(out, h, hi, mid, lo);
-  }
-}
-
-template <int D, int KS>
-__device__ __forceinline__ void fmm_target_operand(bf16x8 (&xb)[fmm_ksteps(D)], int h, const float (&hi)[D + 1],
-                                                   const float (&mid)[D + 1], const float (&lo)[D + 1]) {
-  if constexpr (KS < fmm_ksteps(D)) {
-    fmm_target_fill<D, KS, 0>(xb[KS], h, hi, mid, lo);
-    fmm_target_operand<D, KS + 1>(xb, h, hi, mid, lo);
-  }
-}
 
 // t - (float)pair[0] and t - (float)pair[1] in ONE instruction each: v_fma_mix_f32 reads an f16 half of a register as
 // an fma operand (the compiler folds fma(h, -1, t) back into v_cvt_f32_f16 + v_sub_f32, a third more VALU work in the
@@ -108,10 +84,8 @@ __device__ __forceinline__ float fmm_minus_hi_half(float t, h16x2 pair) {
   return r;
 }
 
-template <int D, int MODE, int TT>
+template <int KS, int MODE, int TT>
 __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs a) {
-  constexpr int KS = fmm_ksteps(D);
-  constexpr int RD = fast_target_row(D);
   constexpr int RB = fmm_row_bytes(KS);
   constexpr int TB = fmm_tile_bytes(KS, MODE);
   constexpr int SB = fmm_stage_bytes(KS, MODE);
@@ -128,22 +102,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
   const int h = lane >> 5;
   const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
 
+  // the B operand of this lane's targets, pre-packed per (target tile, k-step, lane): the kernel depends on the point
+  // dimension only through the number of k-steps
   bf16x8 xb[TT][KS];
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const float* row = a.xr + ((tile0 + tt) * FAST_TILE + r) * RD;
-    float v[RD];
+  for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-    for (int q = 0; q < RD / 4; ++q) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(row + 4 * q);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[4 * q + j] = w[j];
-    }
-    float hi[D + 1], mid[D + 1], lo[D + 1];
-#pragma unroll
-    for (int d = 0; d <= D; ++d) fast_split3f(v[d], hi[d], mid[d], lo[d]);
-    fmm_target_operand<D, 0>(xb[tt], h, hi, mid, lo);
-  }
+    for (int ks = 0; ks < KS; ++ks)
+      xb[tt][ks] = *reinterpret_cast<const bf16x8*>(a.xop + (((tile0 + tt) * KS + ks) * 64 + lane) * 16);
 
   f32x16 acc[TT];
   double accd[TT][NOUT];
@@ -193,7 +159,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
     // The squared distances of tile q + 1 are issued before the kernel values of tile q are worked on: the matrix pipe
     // runs them under the transcendentals and conversions of this very wave (the stage loop is unrolled, so the two
     // register sets swap without copies).
-    constexpr int ST = fmm_stage_tiles(MODE);
+    constexpr int ST = fmm_stage_tiles(KS);
     f32x16 dn[TT];
     auto distances = [&](int q, f32x16 (&d)[TT]) {
       const unsigned char* lt = &lds[buf][q * TB];

@@ -1,29 +1,35 @@
-// Instantiations of fastmm_kernel (kmvp_fastmm.hpp): D = point dimension, MODE = 0 (<= 16 columns) / 1 (<= 32),
-// TT = target tiles of 32 per wave (1 or 2).
+// Instantiations of fastmm_kernel (kmvp_fastmm.hpp): KS = k-steps of the squared-distance product (point dimension D:
+// KS = ceil((6 D + 7) / 16), D <= 39), MODE = 0 (<= 16 columns) / 1 (<= 32), TT = target tiles of 32 per wave (two while
+// KS <= 4).
 #include "kmvp_internal.hpp"
 #include "kmvp_fastmm.hpp"
 
 namespace kmvp {
 
-template <int D, int MODE>
+template <int KS, int MODE>
 static hipError_t launch_tt(int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
   switch (TT) {
-    case 1: hipLaunchKernelGGL((fastmm_kernel<D, MODE, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
-    case 2: hipLaunchKernelGGL((fastmm_kernel<D, MODE, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
+    case 1: hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
+    case 2:
+      if constexpr (KS <= FMM_MAX_KS_TWO_TILES) {
+        hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+        break;
+      }
+      return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-template <int D>
+template <int KS>
 static hipError_t launch_mode(int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
-  return mode ? launch_tt<D, 1>(TT, args, grid, stream) : launch_tt<D, 0>(TT, args, grid, stream);
+  return mode ? launch_tt<KS, 1>(TT, args, grid, stream) : launch_tt<KS, 0>(TT, args, grid, stream);
 }
 
-hipError_t launch_fastmm_gaussian(int D, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
+hipError_t launch_fastmm_gaussian(int KS, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
                                   const char** kernel_name) {
   if (kernel_name) *kernel_name = "fastmm_kernel";
-  switch (D) {
+  switch (KS) {
     case 1: return launch_mode<1>(mode, TT, args, grid, stream);
     case 2: return launch_mode<2>(mode, TT, args, grid, stream);
     case 3: return launch_mode<3>(mode, TT, args, grid, stream);
@@ -32,6 +38,14 @@ hipError_t launch_fastmm_gaussian(int D, int mode, int TT, const FastmmArgs& arg
     case 6: return launch_mode<6>(mode, TT, args, grid, stream);
     case 7: return launch_mode<7>(mode, TT, args, grid, stream);
     case 8: return launch_mode<8>(mode, TT, args, grid, stream);
+    case 9: return launch_mode<9>(mode, TT, args, grid, stream);
+    case 10: return launch_mode<10>(mode, TT, args, grid, stream);
+    case 11: return launch_mode<11>(mode, TT, args, grid, stream);
+    case 12: return launch_mode<12>(mode, TT, args, grid, stream);
+    case 13: return launch_mode<13>(mode, TT, args, grid, stream);
+    case 14: return launch_mode<14>(mode, TT, args, grid, stream);
+    case 15: return launch_mode<15>(mode, TT, args, grid, stream);
+    case 16: return launch_mode<16>(mode, TT, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }

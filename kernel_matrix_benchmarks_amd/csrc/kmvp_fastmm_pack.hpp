@@ -1,5 +1,4 @@
-// Packing kernels of fastmm_kernel (layouts in kmvp_fastmm.hpp; included by kmvp_product.hip only).  The target side
-// is fast_kernel's (pack_fast_targets_kernel).
+// Packing kernels of fastmm_kernel (layouts in kmvp_fastmm.hpp; included by kmvp_product.hip only).
 #pragma once
 #include "kmvp_fast_pack.hpp"
 #include "kmvp_fastmm.hpp"
@@ -12,9 +11,9 @@ __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float
                                         unsigned char* __restrict__ img, int64_t m, int64_t m_stages, int D, int KS,
                                         int MODE, float scale) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m_stages * fmm_stage_tiles(MODE) * FAST_TILE) return;
-  const int64_t stage = j / (fmm_stage_tiles(MODE) * FAST_TILE);
-  const int q = (int)((j / FAST_TILE) % fmm_stage_tiles(MODE));
+  if (j >= m_stages * fmm_stage_tiles(KS) * FAST_TILE) return;
+  const int64_t stage = j / (fmm_stage_tiles(KS) * FAST_TILE);
+  const int q = (int)((j / FAST_TILE) % fmm_stage_tiles(KS));
   const int r = (int)(j % FAST_TILE);
   const int RB = fmm_row_bytes(KS);
   unsigned char* tile = img + stage * (int64_t)fmm_stage_bytes(KS, MODE) + q * fmm_tile_bytes(KS, MODE);
@@ -45,6 +44,52 @@ __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float
   row[6 * D + 5] = one;
   row[6 * D + 6] = one;
   for (int k = 6 * D + 7; k < 16 * KS + 8; ++k) row[k] = zero;  // incl. the 16-byte row pad
+}
+
+// target operands [n_pad / 32][KS][64 lanes] x 16 bytes: lane (r, h) of target tile t holds elements k = 16 ks + 8 h + j
+// (j = 0 .. 7) of target 32 t + r's augmented row -- per d (x_h, x_m, x_h, x_l, x_m, x_h) of the centred scaled coordinate
+// split three ways into bf16, then 1, 1, 1, |x'|^2 h, m, l (accumulated in double, rounded once), -FMM_SHIFT, zeros.
+// One thread per (target, k-step, lane half).
+__global__ void pack_fastmm_targets_kernel(const float* __restrict__ x, const float* __restrict__ centre,
+                                           unsigned char* __restrict__ xop, int64_t n, int64_t n_pad, int D, int KS,
+                                           float scale) {
+  const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_pad * KS * 2) return;
+  const int64_t i = id / (2 * KS);
+  const int ks = (int)((id / 2) % KS), h = (int)(id & 1);
+  double sq = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const float v = i < n ? (x[i * D + d] - centre[d]) * scale : 0.f;
+    sq += (double)v * (double)v;
+  }
+  __bf16 sh, sm, sl;
+  fast_split3((float)sq, sh, sm, sl);
+  bf16x8 out;
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * ks + 8 * h + j;
+    __bf16 e = (__bf16)0.f;
+    if (k < 6 * D) {
+      const int d = k / 6, role = k % 6;
+      const float v = i < n ? (x[i * D + d] - centre[d]) * scale : 0.f;
+      __bf16 vh, vm, vl;
+      fast_split3(v, vh, vm, vl);
+      e = (role == 0 || role == 2 || role == 5) ? vh : ((role == 1 || role == 4) ? vm : vl);
+    } else if (k < 6 * D + 3) {
+      e = (__bf16)1.f;
+    } else if (k == 6 * D + 3) {
+      e = sh;
+    } else if (k == 6 * D + 4) {
+      e = sm;
+    } else if (k == 6 * D + 5) {
+      e = sl;
+    } else if (k == 6 * D + 6) {
+      e = (__bf16)(-(float)FMM_SHIFT);
+    }
+    out[j] = e;
+  }
+  const int64_t tile = i / 32;
+  const int lane = h * 32 + (int)(i % 32);
+  *reinterpret_cast<bf16x8*>(xop + ((tile * KS + ks) * 64 + lane) * 16) = out;
 }
 
 // one block per column: sigma[e] = 2^(14 - ex) with max |b_e| = f 2^ex, f in [0.5, 1): |b sigma| < 2^14, so that the
@@ -97,15 +142,15 @@ __global__ void pack_fastmm_signal_kernel(const float* __restrict__ b, const flo
   const int parts = MODE ? 2 : 1;
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t per_tile = (int64_t)parts * 2 * 64;
-  if (id >= m_stages * fmm_stage_tiles(MODE) * per_tile) return;
+  if (id >= m_stages * fmm_stage_tiles(KS) * per_tile) return;
   const int64_t t = id / per_tile;
   const int w = (int)(id % per_tile);
   const int part = w / 128, g2 = (w / 64) & 1, lane = w & 63;
   const int mrow = lane & 31, h = lane >> 5;
   const int col = MODE ? mrow : (mrow & 15);
   const bool want_lo = MODE ? part == 1 : mrow >= 16;
-  unsigned char* tile = img + (t / fmm_stage_tiles(MODE)) * (int64_t)fmm_stage_bytes(KS, MODE) +
-                        (t % fmm_stage_tiles(MODE)) * fmm_tile_bytes(KS, MODE);
+  unsigned char* tile = img + (t / fmm_stage_tiles(KS)) * (int64_t)fmm_stage_bytes(KS, MODE) +
+                        (t % fmm_stage_tiles(KS)) * fmm_tile_bytes(KS, MODE);
   h16x8 out;
   for (int i = 0; i < 8; ++i) {
     const int64_t j = t * FAST_TILE + 8 * (2 * g2 + (i >> 2)) + 4 * h + (i & 3);

@@ -572,7 +572,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
 }
 
 // Gaussian products with several signal columns, both matrix products on the matrix cores (kmvp_fastmm.hpp): float32,
-// D <= 8, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
+// D <= 39, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
 int run_product_fastmm(kmvp_ctx* c, int sig) {
   const int D = c->D, E = c->E;
   const int NE = sig == SIG_NORM ? E + 1 : E;
@@ -580,7 +580,8 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   const int KS = fmm_ksteps(D);
   const int MODE = NE > 16 ? 1 : 0;
   const bool small = N < SMALL_PROBLEM_TARGETS;
-  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, 2) : (small ? 1 : 2);  // (four tiles: no faster, 256 VGPRs)
+  const int tt_max = KS <= FMM_MAX_KS_TWO_TILES ? 2 : 1;  // (four tiles: no faster, 256 VGPRs)
+  const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, tt_max) : (small ? 1 : tt_max);
   const int64_t SB = fmm_stage_bytes(KS, MODE);
   const float scale = scale_for<float>(K_GAUSSIAN);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
@@ -588,7 +589,7 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   const int64_t n_pad = round_up(N, tile);
   const int64_t tile_blocks = n_pad / tile;
   const int64_t m_tiles = (M + FAST_TILE - 1) / FAST_TILE;
-  const int64_t m_stages = (m_tiles + fmm_stage_tiles(MODE) - 1) / fmm_stage_tiles(MODE);
+  const int64_t m_stages = (m_tiles + fmm_stage_tiles(KS) - 1) / fmm_stage_tiles(KS);
   const int nb_max = std::min(NE, FMM_MAX_COLS);
   int rc;
 
@@ -609,12 +610,11 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   float* sigma = (float*)((char*)c->cell_scale.p + 256);
   double* unscale = (double*)((char*)c->cell_scale.p + 512);
   if (pts_stale) {
-    const int RD = fast_target_row(D);
-    if ((rc = ensure(c, c->xs, (size_t)n_pad * RD * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->xs, (size_t)n_pad * KS * 32))) return rc;
     if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
-    hipLaunchKernelGGL(pack_fast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
-                       centre, (float*)c->xs.p, N, n_pad, D, RD, scale);
-    hipLaunchKernelGGL(pack_fastmm_rows_kernel, dim3(blocks_for(m_stages * fmm_stage_tiles(MODE) * FAST_TILE)), dim3(256), 0,
+    hipLaunchKernelGGL(pack_fastmm_targets_kernel, dim3(blocks_for(n_pad * KS * 2)), dim3(256), 0, c->stream, x_raw,
+                       centre, (unsigned char*)c->xs.p, N, n_pad, D, KS, scale);
+    hipLaunchKernelGGL(pack_fastmm_rows_kernel, dim3(blocks_for(m_stages * fmm_stage_tiles(KS) * FAST_TILE)), dim3(256), 0,
                        c->stream, (const float*)c->y_raw.p, centre, (unsigned char*)c->rec.p, M, m_stages, D, KS, MODE,
                        scale);
     HIP_TRY(c, hipGetLastError());
@@ -629,7 +629,7 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   if ((rc = ensure(c, c->part, (size_t)segments * nb_max * n_pad * sizeof(double)))) return rc;
   if (!one_block && (rc = ensure(c, c->sums, (size_t)NE * n_pad * sizeof(double)))) return rc;
   FastmmArgs a;
-  a.xr = (const float*)c->xs.p;
+  a.xop = (const unsigned char*)c->xs.p;
   a.img = (const unsigned char*)c->rec.p;
   a.unscale = unscale;
   a.part = (double*)c->part.p;
@@ -638,9 +638,9 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   a.seg_stages = seg_stages;
   a.segments = segments;
   a.tile_blocks = (int)tile_blocks;
-  a.chunk_stages = std::max(1, 2 * c->opt_chunk / (FAST_TILE * fmm_stage_tiles(MODE)));
+  a.chunk_stages = std::max(1, 2 * c->opt_chunk / (FAST_TILE * fmm_stage_tiles(KS)));
   const dim3 grid((unsigned)(tile_blocks * segments));
-  const int64_t pieces = m_stages * fmm_stage_tiles(MODE) * (MODE ? 2 : 1) * 2 * 64;
+  const int64_t pieces = m_stages * fmm_stage_tiles(KS) * (MODE ? 2 : 1) * 2 * 64;
   HIP_TRY(c, mark(c, 0));
   for (int col0 = 0; col0 < NE; col0 += FMM_MAX_COLS) {
     const int nb = std::min(FMM_MAX_COLS, NE - col0);
@@ -653,8 +653,8 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
       HIP_TRY(c, hipGetLastError());
     }
     a.NE = nb;
-    hipError_t le = launch_fastmm_gaussian(D, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
-    if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2 or 4");
+    hipError_t le = launch_fastmm_gaussian(KS, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
+    if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "no fastmm_kernel for this dimension / tile count");
     HIP_TRY(c, le);
     if (!one_block) {
       const int Ek = std::min(nb, E - col0);  // signal columns of the block; the one beyond them is the denominator
@@ -1700,7 +1700,7 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       (c->opt_fast < 0 || c->opt_fast == 1 || c->opt_fast == 3)) {
     // Several signal columns (low-D attention with E value channels).  Two forms on the matrix cores:
     //   fastmm_kernel  the tile of kernel values goes back to the matrix pipe for the product with the signal: up to 32
-    //                  columns per pass at a cost per pair that does not depend on the column count (D <= 8);
+    //                  columns per pass at a cost per pair that does not depend on the column count (D <= 39);
     //   cellmm_kernel  one launch per column where the cell form applies (same rule as for E = 1 below; D <= 3) --
     //                  a seventh of fastmm's cost per pair and column where the cells are well filled.
     // auto takes the cheaper one by the tile counts (picoseconds per 32 x 32 tile on the whole chip, measured at

@@ -266,7 +266,7 @@ def test_cellmm_kernel_with_several_signal_columns_matches_reference(case, expec
         assert got.shape == truth.shape and rel_err(got, truth) <= tol, (tiles, rel_err(got, truth), tol)
 
 
-FMM_MULTI = [c for c in CASES if c["D"] <= 8 and c["kernel"] == "gaussian" and c["E"] > 1 and not c["density_estimation"]]
+FMM_MULTI = [c for c in CASES if c["D"] <= 39 and c["kernel"] == "gaussian" and c["E"] > 1 and not c["density_estimation"]]
 
 
 @pytest.mark.parametrize("case", FMM_MULTI, ids=[c["name"] for c in FMM_MULTI])
@@ -288,15 +288,15 @@ def test_fastmm_kernel_with_several_signal_columns_matches_reference(case, expec
     assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
 
 
-@pytest.mark.parametrize("D,E,norm", [(3, 40, True), (2, 32, True), (8, 33, False), (1, 17, False), (7, 64, True)])
+@pytest.mark.parametrize("D,E,norm", [(3, 40, True), (2, 32, True), (8, 33, False), (1, 17, False), (7, 64, True), (16, 20, True), (39, 5, False)])
 def test_fastmm_kernel_column_blocks_and_ragged_sizes(D, E, norm):
     """More than 32 columns run as blocks of 32 (the denominator is the last column of the last block); N and M are
     multiples of nothing; the columns' scales span twelve decades (each column is scaled by its own power of two before
     the f16 split, so that a small column is as accurate as a large one).  Checked against the float64 oracle."""
     rng = np.random.RandomState(100 * D + E)
     n, m = 1237, 2051
-    y = rng.rand(m, D)
-    x = rng.rand(n, D)
+    y = rng.rand(m, D) / np.sqrt(max(D, 3) / 3.0)
+    x = rng.rand(n, D) / np.sqrt(max(D, 3) / 3.0)
     b = rng.randn(m, E) * 10.0 ** rng.randint(-6, 7, size=E)
     algo = MI355XProduct(kernel="gaussian", dimension=D, normalize_rows=norm, precision="float32", fast_sqdists=True)
     try:
@@ -957,6 +957,24 @@ def test_single_rank_rccl_communicator():
         ctx.close()
     want = kmvp_oracle.product(kernel="absolute-exponential", source_points=yd, source_signal=bd, normalize_rows=True)
     assert rel_err(got, want) <= TOL_BF16
+    # several signal columns on the matrix cores (one block / three blocks of 32 columns), through the same exchange
+    for kernel, fast, E, norm, kname in (("gaussian", 1, 5, True, "fastmm_kernel"), ("gaussian", 1, 70, False, "fastmm_kernel"),
+                                         ("absolute-exponential", 2, 5, True, "cfastmm_kernel"),
+                                         ("absolute-exponential", 2, 70, True, "cfastmm_kernel")):
+        bm = np.random.RandomState(E).randn(n, E)
+        ctx = _lib.Context(0)
+        try:
+            ctx.comm_init(_lib.comm_unique_id(), 0, 1)
+            ctx.set_option("fast_sqdists", fast)
+            ctx.set_points(y.astype(np.float32), None, _lib.KMVP_F32)
+            ctx.set_signal(bm.astype(np.float32))
+            ctx.run(kernel, norm)
+            got = ctx.get_result(n, E)
+            assert ctx.last_kernel_name == kname
+        finally:
+            ctx.close()
+        want = kmvp_oracle.product(kernel=kernel, source_points=y, source_signal=bm, normalize_rows=norm)
+        assert rel_err(got, want) <= TOL32, (kernel, kname, E)
 
 
 def test_abi_error_behaviour():
