@@ -1615,3 +1615,18 @@ def test_randomised_parity_sweep():
     seen, failures = fuzz.sweep(250, 2024, verbose=False)
     assert not failures, failures
     assert {"lowd_kernel", "lowd_mid_kernel", "fast_kernel", "fastmm_kernel", "cfast_kernel", "cfastmm_kernel"} <= set(seen), seen
+
+
+def test_randomised_solver_sweep():
+    """tools/fuzz_solver.py: 60 random solves (kernel, n 40 .. 40000, D, one or three right-hand sides, float32 / float64,
+    rtol, mixed-precision refinement; at most 600 iterations).  Whatever is reported as converged must have a true float64
+    residual within 2 rtol (oracle), and ill-conditioned systems that do not get there must say so."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_solver", os.path.join(root, "tools", "fuzz_solver.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    stats, failures = fuzz.sweep(60, 5, verbose=False)
+    assert not failures, failures
+    assert stats["converged"] >= 10 and stats["not_converged"] >= 1, stats
