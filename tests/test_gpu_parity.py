@@ -1630,3 +1630,32 @@ def test_randomised_solver_sweep():
     stats, failures = fuzz.sweep(60, 5, verbose=False)
     assert not failures, failures
     assert stats["converged"] >= 10 and stats["not_converged"] >= 1, stats
+
+
+@pytest.mark.parametrize("kernel,side,want_kernel", [("absolute-exponential", 6.0, "cfastmm_kernel"),
+                                                     ("gaussian", 2.4, "fastmm_kernel"), ("gaussian", 9.0, "cfastmm_kernel")])
+def test_multi_column_kernels_as_solver_operators(kernel, side, want_kernel):
+    """K B = A with five right-hand sides in float32: the CG iterate is an (M, 5) signal, so every operator application
+    inside the device-resident iteration (hipGraph replay for long solves) is a multi-column product -- fastmm_kernel inside
+    the radius rule, cfastmm_kernel outside it and for exp(-r).  The verdict is checked against the float64 oracle."""
+    n, E, rtol = 3000, 5, 1e-3
+    rs = np.random.RandomState(int(side * 10))
+    y = (rs.rand(n, 3) * side).astype(np.float32).astype(np.float64)
+    a = rs.randn(n, E).astype(np.float32).astype(np.float64)
+    algo = MI355XSolver(kernel=kernel, dimension=3, precision="float32", rtol=rtol, maxit=2000)
+    try:
+        algo.prepare_data(source_points=y)
+        algo.fit()
+        algo.prepare_query(target_signal=a)
+        algo.query()
+        b = algo.get_result()
+        info = algo.get_additional()
+    finally:
+        algo.done()
+    assert info["device_kernel"] == want_kernel, info
+    Kb = kmvp_oracle.product(kernel=kernel, source_points=y, source_signal=b)
+    res = float(np.max(np.linalg.norm(Kb - a, axis=0) / np.linalg.norm(a, axis=0)))
+    if info["cg_converged"]:
+        assert res <= 2 * rtol, (res, info)
+    else:  # an ill-conditioned draw: it must have said so, with a residual that is the true one
+        assert info["cg_relative_residual"] > rtol and abs(res - info["cg_relative_residual"]) <= 0.5 * res, (res, info)
