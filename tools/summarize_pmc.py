@@ -10,7 +10,7 @@ for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), rec
         acc[k][c].append(v)
 lines = []
 for k in sorted(acc):
-    if not any(t in k for t in ("mfma_kernel", "mfma_pipe_kernel", "fast_kernel", "lowd_kernel", "cfast_kernel", "cell_kernel", "cell64_kernel", "cellmm_kernel")):
+    if not any(t in k for t in ("mfma_kernel", "mfma_pipe_kernel", "fast_kernel", "lowd_kernel", "cfast_kernel", "cell_kernel", "cell64_kernel", "cellmm_kernel", "fastmm_kernel", "cfastmm_kernel")):
         continue
     lines.append(k)
     for c in sorted(acc[k]):
