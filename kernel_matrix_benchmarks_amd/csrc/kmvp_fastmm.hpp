@@ -11,7 +11,7 @@
 //                                                                    that subtracts FMM_SHIFT: T = 2^15 exp(-s));
 //                                                                    D <= 39, KS = ceil((6 D + 7) / 16) <= 16
 //   T  = exp2(-S)                                   16 v_exp_f32 per lane: the one transcendental per PAIR
-//   T  = T_h + T_l  (two f16: 11 + 11 bits)         v_cvt_pk_f16_f32, subtract, v_cvt_pk_f16_f32
+//   T  = T_h + T_l  (two f16: 11 + 11 bits)         v_cvt_pk_f16_f32, v_fma_mix_f32 (T - T_h), v_cvt_pk_f16_f32
 //   O (32 columns x 32 targets) += B'^T T           f16 MFMAs, fp32 accumulators: up to 32 signal columns at once
 //
 // The S tile comes out of the MFMA with the TARGET on the lane and 16 sources in the lane's registers, which IS the
@@ -21,12 +21,13 @@
 //   MODE 0 (<= 16 columns): the A operand holds b_h in rows 0..15 and b_l in rows 16..31 -> two MFMAs per 16 sources
 //          (with T_h and T_l), rows e and e + 16 added when the accumulator is folded;
 //   MODE 1 (<= 32 columns): A_h, A_l separately -> three MFMAs (A_h T_h, A_l T_h, A_h T_l).
-// Every FMM_CHUNK_TILES source tiles the fp32 accumulators are folded into fp64 registers (the chain of MFMA
-// accumulations stays short), and the partial sums leave as fp64 like everywhere else.
+// Every 2 x "chunk" sources (option; default 32 source tiles) the fp32 accumulators are folded into fp64 registers (the
+// chain of MFMA accumulations stays short), and the partial sums leave as fp64 like everywhere else.
 //
 // Per 32 x 32 pairs and lane: 16 v_exp_f32 + 16 v_cvt_pk_f16_f32 + 16 v_fma_mix_f32 against 16 (1 + E) FMAs +
-// 16 v_exp_f32 of a VALU sum, and 2 + 4 (6) MFMAs of 8 passes beside them (331 issue cycles, measured 335).  Error: T and b are carried to 2^-22, s as in fast_kernel
-// (eps32 (|x'|^2 + |y'|^2), clouds inside the radius rule) -- measured in tests/test_gpu_parity.py.
+// 16 v_exp_f32 of a VALU sum, and KS + 4 (6) MFMAs of 8 passes beside them (331 issue cycles, measured
+// 335).  Error: T and b are carried to 2^-22, s as in fast_kernel (eps32 (|x'|^2 + |y'|^2), clouds inside the radius
+// rule) -- measured in tests/test_gpu_parity.py.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,7 +46,6 @@ constexpr int FMM_MAX_KS_TWO_TILES = 4;  // two target tiles per wave while the 
 // source tiles per LDS stage: four while a stage stays below ~30 KiB, two up to K = 144, one beyond
 __host__ __device__ constexpr int fmm_stage_tiles(int KS) { return KS <= 4 ? 4 : (KS <= 9 ? 2 : 1); }
 constexpr int FMM_SHIFT = 15;        // T = 2^15 exp(-s) <= 32768 < 65504: small kernel values stay normal f16 numbers
-constexpr int FMM_CHUNK_TILES = 32;  // source tiles per fp32 accumulation chain (default; FastmmArgs::chunk_stages)
 constexpr int FMM_MAX_COLS = 32;
 
 __host__ __device__ constexpr int fmm_ksteps(int D) { return (6 * D + 7 + 15) / 16; }
