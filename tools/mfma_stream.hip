@@ -15,8 +15,17 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned seed) {
   f16x8 a, b[8];
   unsigned s = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
   auto next = [&]() { s = s * 1664525u + 1013904223u; return RANDOM ? (float)((s >> 8) & 0xffff) / 65536.f - 0.5f : 0.f; };
-  for (int j = 0; j < 8; ++j) a[j] = (_Float16)next();
-  for (int t = 0; t < 8; ++t) for (int j = 0; j < 8; ++j) b[t][j] = (_Float16)next();
+  // RANDOM 2 / 3: the low 4 / 7 mantissa bits of every f16 operand element cleared; 4: every second k-slot zero
+  auto trim = [&](float v, int j) {
+    _Float16 hv = (_Float16)v;
+    unsigned short bits = __builtin_bit_cast(unsigned short, hv);
+    if (RANDOM == 2) bits &= 0xfff0u;
+    if (RANDOM == 3) bits &= 0xff80u;
+    if (RANDOM == 4 && (j & 1)) bits = 0;
+    return __builtin_bit_cast(_Float16, bits);
+  };
+  for (int j = 0; j < 8; ++j) a[j] = trim(next(), j);
+  for (int t = 0; t < 8; ++t) for (int j = 0; j < 8; ++j) b[t][j] = trim(next(), j);
   f32x16 acc[8];
   for (int t = 0; t < 8; ++t) for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
   for (int it = 0; it < iters; ++it) {
@@ -24,7 +33,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, unsigned seed) {
     for (int m = 0; m < 8; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[NB == 1 ? 0 : m], acc[m], 0, 0, 0);
     if (RANDOM) {  // keep the operand changing from trip to trip, as a rebuilt A does (one VALU instruction per register)
       auto w = __builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, a);
-      w[it & 3] ^= 0x00010001u << (it & 7);
+      w[it & 3] ^= (RANDOM == 3 ? 0x00800080u : (RANDOM == 2 ? 0x00100010u : 0x00010001u)) << (it & 7);
+      if (RANDOM == 4) w[it & 3] &= 0x0000ffffu;
       a = __builtin_bit_cast(f16x8, w);
     }
   }
@@ -59,6 +69,9 @@ int main() {
     if (run<8, 0>("eight B, zero data", w)) return 1;
     if (run<1, 1>("one B, random data", w)) return 1;
     if (run<8, 1>("eight B, random data", w)) return 1;
+    if (run<8, 2>("eight B, random data, 7-bit mantissas", w)) return 1;
+    if (run<8, 3>("eight B, random data, 4-bit mantissas", w)) return 1;
+    if (run<8, 4>("eight B, random data, odd k-slots zero", w)) return 1;
   }
   return 0;
 }
