@@ -1046,18 +1046,29 @@ void cell_load_grid(const kmvp_ctx* c, CellGrid& grid) {
   }
 }
 
-// tiles a cloud with these sorted cell keys occupies when every cell gets a multiple of `mult` tiles
-int64_t cell_count_tiles(const std::vector<unsigned>& keys, int mult) {
+// Tiles of the two target lists cell_tiles_split() builds for groups of TT (before the padding to whole workgroups)
+void cell_split_count(const std::vector<unsigned>& keys, int TT, int64_t* n_main, int64_t* n_rest) {
   const int64_t n = (int64_t)keys.size();
-  int64_t tiles = 0;
+  const int RT = 2;
+  *n_main = *n_rest = 0;
   for (int64_t p = 0; p < n;) {
     int64_t e = p + 1;
     while (e < n && keys[(size_t)e] == keys[(size_t)p]) ++e;
-    tiles += round_up((e - p + CELL_TILE - 1) / CELL_TILE, mult);
+    const int64_t tiles = (e - p + CELL_TILE - 1) / CELL_TILE;
+    const int64_t rem = tiles % TT;
+    if (TT > RT && rem > 0 && rem <= TT / 2) {
+      *n_main += tiles - rem;
+      *n_rest += round_up(rem, RT);
+    } else {
+      *n_main += round_up(tiles, TT);
+    }
     p = e;
   }
-  return tiles;
 }
+
+// picoseconds per 32 x 32 tile of pairs of the float32 cell kernels, whole chip, by the tiles a wavefront owns
+// (cellmm_kernel at the headline shape: TT = 8 / 4 / 2: 26.9 / 30.7 / 44.2 ms for 1.03e9 tiles)
+inline double cell_ps_per_tile(int TT) { return TT >= 8 ? CMM_PS_PER_TILE_MAIN : (TT >= 4 ? CMM_PS_PER_TILE_TT4 : CMM_PS_PER_TILE_REST); }
 
 // Grid and cell order of both clouds for the current points (cached per points version).
 // TT > 0: target tiles per wavefront as requested; TT == 0: the largest of 8, 4, 2 whose padding of the
@@ -1082,11 +1093,16 @@ int cell_prepare(kmvp_ctx* c, int TT) {
   if ((rc = cell_tiles(c, keys, 1, c->cell_sgrp, &c->cell_m_tiles))) return rc;
   if (!c->same_points && (rc = cell_sort(c, c->x_raw.p, c->N, grid, c->cell_tperm, keys))) return rc;
   if (TT == 0) {
-    TT = 2;
-    for (int t : {8, 4}) {
-      if ((double)cell_count_tiles(keys, t) * CELL_TILE <= CELL_AUTO_MAX_PAD * (double)c->N) {
+    // auto: the group size whose two lists cost least (sparse cells of 3 - 5 tiles: groups of four and a leftover list
+    // beat groups of two; dense cells: groups of eight)
+    double best = INFINITY;
+    for (int t : {8, 4, 2}) {
+      int64_t nm, nr;
+      cell_split_count(keys, t, &nm, &nr);
+      const double cost = cell_ps_per_tile(t) * (double)nm + cell_ps_per_tile(2) * (double)nr;
+      if (cost < best) {
+        best = cost;
         TT = t;
-        break;
       }
     }
   }
@@ -1718,7 +1734,7 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       if (c->cell_state == 1 && (c->opt_fast == 3 || cell_padding(c) <= CELL_AUTO_MAX_PAD) &&
           cellmm_wlog2(c) <= CMM_MAX_WLOG2)
         t_cell = (double)cols * (double)c->cell_m_tiles *
-                 (CMM_PS_PER_TILE_MAIN * (double)c->cell_n_main + CMM_PS_PER_TILE_REST * (double)c->cell_n_rest);
+                 (cell_ps_per_tile(c->cell_tt) * (double)c->cell_n_main + cell_ps_per_tile(2) * (double)c->cell_n_rest);
     }
     if (fmm_ok) {
       const double tiles = std::ceil((double)c->N / FAST_TILE) * std::ceil((double)c->M / FAST_TILE);
