@@ -288,7 +288,8 @@ def test_fastmm_kernel_with_several_signal_columns_matches_reference(case, expec
     assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
 
 
-@pytest.mark.parametrize("D,E,norm", [(3, 40, True), (2, 32, True), (8, 33, False), (1, 17, False), (7, 64, True), (16, 20, True), (39, 5, False)])
+@pytest.mark.parametrize("D,E,norm", [(3, 40, True), (2, 32, True), (8, 33, False), (1, 17, False), (7, 64, True), (16, 20, True), (39, 5, False),
+                                         (3, 16, True), (5, 16, True), (3, 16, False)])
 def test_fastmm_kernel_column_blocks_and_ragged_sizes(D, E, norm):
     """More than 32 columns run as blocks of 32 (the denominator is the last column of the last block); N and M are
     multiples of nothing; the columns' scales span twelve decades (each column is scaled by its own power of two before
