@@ -916,6 +916,34 @@ def test_source_shard_with_global_offset_matches_oracle():
         assert rel_err(total, full) <= TOL64
 
 
+def test_source_shards_of_the_multi_column_kernels_add_up():
+    """The same for float32 products with several signal columns (fastmm_kernel / cfastmm_kernel; every rank scales the
+    columns of ITS shard of the signal by its own powers of two): three uneven source shards against the whole product."""
+    rs = np.random.RandomState(21)
+    n, m, E = 700, 1300, 6
+    y = rs.rand(m, 3).astype(np.float32)
+    x = rs.rand(n, 3).astype(np.float32)
+    b = (rs.randn(m, E) * 10.0 ** rs.randint(-3, 4, size=E)).astype(np.float32)
+    for kernel, fast, kname in (("gaussian", 1, "fastmm_kernel"), ("absolute-exponential", 2, "cfastmm_kernel")):
+        total = np.zeros((n, E))
+        for lo, hi in ((0, 33), (33, 700), (700, m)):
+            ctx = _lib.Context(0)
+            try:
+                ctx.set_option("partial_shard", 1)
+                ctx.set_option("fast_sqdists", fast)
+                ctx.set_points(np.ascontiguousarray(y[lo:hi]), x, _lib.KMVP_F32, j_offset=lo, M_total=m)
+                ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
+                ctx.run(kernel, False)
+                total += ctx.get_result(n, E)
+                assert ctx.last_kernel_name == kname
+            finally:
+                ctx.close()
+        full = kmvp_oracle.product(kernel=kernel, source_points=y.astype(np.float64), target_points=x.astype(np.float64),
+                                   source_signal=b.astype(np.float64))
+        col_err = np.abs(total - full).max(axis=0) / np.abs(full).max(axis=0)
+        assert col_err.max() <= TOL32, (kernel, col_err)
+
+
 def test_single_rank_rccl_communicator():
     """kmvp_comm_get_unique_id / kmvp_comm_init / ncclAllReduce with world == 1 on the one GPU.
     With a communicator attached every path goes through the exchange in the canonical unpadded
