@@ -660,6 +660,30 @@ def test_clusters_far_apart_and_non_finite_points():
             assert rel_err(np.delete(got, 5, axis=0), np.delete(want, 5, axis=0)) <= TOL32, (kernel, extra["device_kernel"])
 
 
+def test_non_finite_points_with_several_signal_columns():
+    """The same non-finite inputs through the multi-column matrix-core kernels (a source at infinity: zero contribution to
+    every column; a NaN target coordinate: a NaN row), plain and normalised, against the oracle."""
+    rs = np.random.RandomState(12)
+    y = rs.rand(1500, 3)
+    y[7] = np.inf
+    x = rs.rand(700, 3)
+    x[5, 1] = np.nan
+    b = rs.randn(1500, 6)
+    for kernel in ("gaussian", "absolute-exponential"):
+        for norm in (False, True):
+            with np.errstate(all="ignore"):
+                want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b,
+                                           normalize_rows=norm)
+            assert np.isnan(want[5]).all() and np.isfinite(np.delete(want, 5, axis=0)).all()
+            # (not fast_sqdists=True: the one-centre expansion turns an infinite point into inf - inf for every pair, as
+            # the reference's own fast form does, bruteforce.py:36-49)
+            for opts in (dict(), dict(fast_sqdists="centred")):
+                got, extra = run_plugin(dict(kernel=kernel, D=3, normalize_rows=norm), y, x, b, "float32", **opts)
+                assert extra["device_kernel"] in ("fastmm_kernel", "cfastmm_kernel"), extra
+                assert np.isnan(got[5]).all(), (kernel, norm, extra["device_kernel"])
+                assert rel_err(np.delete(got, 5, axis=0), np.delete(want, 5, axis=0)) <= TOL32, (kernel, norm, extra["device_kernel"])
+
+
 def test_random_shapes_flags_and_precisions():
     """Seeded sweep over shapes the golden set does not hold: every dispatch decision (difference /
     global-centre / per-group-centre / generic kernels, small-problem launch shapes, ragged tiles,
