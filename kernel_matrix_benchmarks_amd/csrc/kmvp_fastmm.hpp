@@ -9,7 +9,7 @@
 //
 //   S  (32 sources x 32 targets) = Y~ X~^T          KS bf16 MFMAs   (operands as in kmvp_fast.hpp, plus one column
 //                                                                    that subtracts FMM_SHIFT: T = 2^15 exp(-s));
-//                                                                    D <= 39, KS = ceil((6 D + 7) / 16) <= 16
+//                                                                    D <= 64, KS = ceil((6 D + 7) / 16) <= 25
 //   T  = exp2(-S)                                   16 v_exp_f32 per lane: the one transcendental per PAIR
 //   T  = T_h + T_l  (two f16: 11 + 11 bits)         v_cvt_pk_f16_f32, v_fma_mix_f32 (T - T_h), v_cvt_pk_f16_f32
 //   O (32 columns x 32 targets) += B'^T T           f16 MFMAs, fp32 accumulators: up to 32 signal columns at once
@@ -40,8 +40,9 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef float fmm_f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int FMM_MAX_D = 39;  // K = 6 D + 7 <= 241: 16 k-steps of 16 (fast_kernel's range)
-constexpr int FMM_MAX_KS = 16;
+constexpr int FMM_MAX_D = 64;  // K = 6 D + 7 <= 391: 25 k-steps of 16 (the operands of one target tile: 100 VGPRs; the
+                               // clouds' centre buffer holds 64 dimensions)
+constexpr int FMM_MAX_KS = 25;
 constexpr int FMM_MAX_KS_TWO_TILES = 4;  // two target tiles per wave while the operands are small (D <= 9)
 // source tiles per LDS stage: four while a stage stays below ~30 KiB, two up to K = 144, one beyond
 __host__ __device__ constexpr int fmm_stage_tiles(int KS) { return KS <= 4 ? 4 : (KS <= 9 ? 2 : 1); }

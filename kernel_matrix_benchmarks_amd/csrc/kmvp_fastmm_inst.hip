@@ -1,5 +1,5 @@
 // Instantiations of fastmm_kernel (kmvp_fastmm.hpp): KS = k-steps of the squared-distance product (point dimension D:
-// KS = ceil((6 D + 7) / 16), D <= 39), MODE = 0 (<= 16 columns) / 1 (<= 32), TT = target tiles of 32 per wave (two while
+// KS = ceil((6 D + 7) / 16), D <= 64), MODE = 0 (<= 16 columns) / 1 (<= 32), TT = target tiles of 32 per wave (two while
 // KS <= 4).
 #include "kmvp_internal.hpp"
 #include "kmvp_fastmm.hpp"
@@ -46,6 +46,15 @@ hipError_t launch_fastmm_gaussian(int KS, int mode, int TT, const FastmmArgs& ar
     case 14: return launch_mode<14>(mode, TT, args, grid, stream);
     case 15: return launch_mode<15>(mode, TT, args, grid, stream);
     case 16: return launch_mode<16>(mode, TT, args, grid, stream);
+    case 17: return launch_mode<17>(mode, TT, args, grid, stream);
+    case 18: return launch_mode<18>(mode, TT, args, grid, stream);
+    case 19: return launch_mode<19>(mode, TT, args, grid, stream);
+    case 20: return launch_mode<20>(mode, TT, args, grid, stream);
+    case 21: return launch_mode<21>(mode, TT, args, grid, stream);
+    case 22: return launch_mode<22>(mode, TT, args, grid, stream);
+    case 23: return launch_mode<23>(mode, TT, args, grid, stream);
+    case 24: return launch_mode<24>(mode, TT, args, grid, stream);
+    case 25: return launch_mode<25>(mode, TT, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -69,7 +69,7 @@ hipError_t launch_fast_invdist(int D, int sig, int TT, const FastArgs& args, dim
                                hipStream_t stream, const char** kernel_name);
 
 
-// both products on the matrix cores (kmvp_fastmm.hpp): Gaussian, float32, D <= 39, several signal columns
+// both products on the matrix cores (kmvp_fastmm.hpp): Gaussian, float32, D <= 64, several signal columns (one column beyond D = 39)
 // cost model of the auto choice between the two (ps per 32 x 32 tile of pairs, whole chip; tools/fmm_probe.py)
 constexpr double FMM_PS_PER_TILE_16 = 180.0, FMM_PS_PER_TILE_32 = 225.0;
 constexpr double CMM_PS_PER_TILE_MAIN = 26.0, CMM_PS_PER_TILE_TT4 = 30.0, CMM_PS_PER_TILE_REST = 48.0;

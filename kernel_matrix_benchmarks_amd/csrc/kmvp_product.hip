@@ -572,7 +572,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
 }
 
 // Gaussian products with several signal columns, both matrix products on the matrix cores (kmvp_fastmm.hpp): float32,
-// D <= 39, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
+// D <= 64, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
 int run_product_fastmm(kmvp_ctx* c, int sig) {
   const int D = c->D, E = c->E;
   const int NE = sig == SIG_NORM ? E + 1 : E;
@@ -1591,7 +1591,7 @@ int measure_clouds(kmvp_ctx* c, int dtype, int64_t M, int64_t N, int D) {
   c->cloud_radius2 = INFINITY;
   // float32: inputs of the split-bf16 paths and of their "auto" rule; float64: the grid of the cell path (D <= 3)
   const bool f64_cells = dtype == KMVP_F64 && D <= CELL_MAX_D;
-  if ((dtype != KMVP_F32 && !f64_cells) || D > FAST_MAX_D || M <= 0 || N <= 0) return KMVP_OK;
+  if ((dtype != KMVP_F32 && !f64_cells) || D > FMM_MAX_D || M <= 0 || N <= 0) return KMVP_OK;  // (aux holds D <= 64 centres)
   int rc;
   if ((rc = ensure(c, c->aux, (FAST_AUX_FLOATS + 2 * (size_t)FAST_BBOX_BLOCKS * D) * sizeof(float)))) return rc;
   float* part = (float*)c->aux.p + FAST_AUX_FLOATS;
@@ -1712,11 +1712,12 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   }
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
-  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && !c->density && c->E > 1 && c->centre_ver == c->points_ver &&
-      (c->opt_fast < 0 || c->opt_fast == 1 || c->opt_fast == 3)) {
-    // Several signal columns (low-D attention with E value channels).  Two forms on the matrix cores:
+  if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && !c->density && (c->E > 1 || c->D > FAST_MAX_D) &&
+      c->centre_ver == c->points_ver && (c->opt_fast < 0 || c->opt_fast == 1 || c->opt_fast == 3)) {
+    // Several signal columns (low-D attention with E value channels) -- and single columns beyond fast_kernel's D = 39,
+    // which fastmm_kernel serves up to D = 64.  Two forms on the matrix cores:
     //   fastmm_kernel  the tile of kernel values goes back to the matrix pipe for the product with the signal: up to 32
-    //                  columns per pass at a cost per pair that does not depend on the column count (D <= 39);
+    //                  columns per pass at a cost per pair that does not depend on the column count (D <= 64);
     //   cellmm_kernel  one launch per column where the cell form applies (same rule as for E = 1 below; D <= 3) --
     //                  a seventh of fastmm's cost per pair and column where the cells are well filled.
     // auto takes the cheaper one by the tile counts (picoseconds per 32 x 32 tile on the whole chip, measured at

@@ -266,7 +266,7 @@ def test_cellmm_kernel_with_several_signal_columns_matches_reference(case, expec
         assert got.shape == truth.shape and rel_err(got, truth) <= tol, (tiles, rel_err(got, truth), tol)
 
 
-FMM_MULTI = [c for c in CASES if c["D"] <= 39 and c["kernel"] == "gaussian" and c["E"] > 1 and not c["density_estimation"]]
+FMM_MULTI = [c for c in CASES if c["D"] <= 64 and c["kernel"] == "gaussian" and c["E"] > 1 and not c["density_estimation"]]
 
 
 @pytest.mark.parametrize("case", FMM_MULTI, ids=[c["name"] for c in FMM_MULTI])
@@ -289,7 +289,7 @@ def test_fastmm_kernel_with_several_signal_columns_matches_reference(case, expec
 
 
 @pytest.mark.parametrize("D,E,norm", [(3, 40, True), (2, 32, True), (8, 33, False), (1, 17, False), (7, 64, True), (16, 20, True), (39, 5, False),
-                                         (3, 16, True), (5, 16, True), (3, 16, False)])
+                                         (3, 16, True), (5, 16, True), (3, 16, False), (64, 33, True), (50, 1, False), (40, 2, True)])
 def test_fastmm_kernel_column_blocks_and_ragged_sizes(D, E, norm):
     """More than 32 columns run as blocks of 32 (the denominator is the last column of the last block); N and M are
     multiples of nothing; the columns' scales span twelve decades (each column is scaled by its own power of two before
