@@ -401,11 +401,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_kernel(const LowdArgs<real
 // through wave-uniform loads (scalar cache), fp32 sums are folded into fp64 every MID_CHUNK sources,
 // signal columns go in blocks of 8.
 constexpr int MID_CHUNK = 64;
+// Signal columns per pass over the sources (the squared distances are recomputed per pass): 8, or 32 where the
+// registers allow it -- float32 rows of up to 64 coordinates with more than 8 columns (E = 64 at D = 64: two passes
+// instead of eight).  The host pads the signal rows to a multiple of it.
+__host__ __device__ constexpr int lowd_mid_colblock(int real_bytes, int D, int E) {
+  return (real_bytes == 4 && D <= 64 && E > 8) ? 32 : 8;
+}
 
-template <int KERNEL, int SIG, typename real, int DCH>
+template <int KERNEL, int SIG, typename real, int DCH, int EBW = 8>
 __global__ void __launch_bounds__(BLOCK_THREADS) lowd_mid_kernel(
     const real* __restrict__ x /* (N, 8 DCH) */, const real* __restrict__ y /* (M, 8 DCH) */,
-    const real* __restrict__ b /* (M, EP), EP = 8 ceil(E / 8), zero padded; unused for density */,
+    const real* __restrict__ b /* (M, EP), EP = EBW ceil(E / EBW), zero padded; unused for density */,
     double* __restrict__ part, int64_t n, int64_t n_pad, int64_t m, int E, int EP, int NE, int segments,
     int64_t seg_len, int64_t j_offset, int64_t m_total) {
   constexpr int DMAX = 8 * DCH;
@@ -430,16 +436,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_mid_kernel(
   const int64_t j0 = (int64_t)seg * seg_len;
   int64_t j1 = j0 + seg_len;
   if (j1 > m) j1 = m;
-  const int blocks = (SIG == SIG_DENSITY) ? 1 : EP / 8;  // passes over the sources, 8 signal columns each
+  const int blocks = (SIG == SIG_DENSITY) ? 1 : EP / EBW;  // passes over the sources, EBW signal columns each
   for (int blk = 0; blk < blocks; ++blk) {
-    double accd[8], dend = 0.0;
+    double accd[EBW], dend = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) accd[q] = 0.0;
+    for (int q = 0; q < EBW; ++q) accd[q] = 0.0;
     for (int64_t jc = j0; jc < j1; jc += MID_CHUNK) {
       const int64_t jend = jc + MID_CHUNK < j1 ? jc + MID_CHUNK : j1;
-      real acc[8], den = (real)0;
+      real acc[EBW], den = (real)0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] = (real)0;
+      for (int q = 0; q < EBW; ++q) acc[q] = (real)0;
       for (int64_t j = jc; j < jend; ++j) {
         const real* __restrict__ yrow = y + j * DMAX;  // wave-uniform address
         real s = 0;
@@ -451,21 +457,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS) lowd_mid_kernel(
         real k = kval<KERNEL>(s, exp_tab);
         if constexpr (KERNEL == K_INVDIST) k = (j == jz) ? (real)0 : k;
         if constexpr (SIG != SIG_DENSITY) {
-          const real* __restrict__ brow = b + j * EP + 8 * blk;
+          const real* __restrict__ brow = b + j * EP + EBW * blk;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc[q] = fma(k, brow[q], acc[q]);  // padded columns: k * 0
+          for (int q = 0; q < EBW; ++q) acc[q] = fma(k, brow[q], acc[q]);  // padded columns: k * 0
         }
         if constexpr (SIG != SIG_PRODUCT) den += k;  // denominator / density
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) accd[q] += (double)acc[q];
+      for (int q = 0; q < EBW; ++q) accd[q] += (double)acc[q];
       dend += (double)den;
     }
     if (i < n_pad) {
       if constexpr (SIG != SIG_DENSITY) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (8 * blk + q < E) part[((int64_t)seg * NE + 8 * blk + q) * n_pad + i] = accd[q];
+        for (int q = 0; q < EBW; ++q)
+          if (EBW * blk + q < E) part[((int64_t)seg * NE + EBW * blk + q) * n_pad + i] = accd[q];
       }
       if (SIG != SIG_PRODUCT && blk == 0) part[((int64_t)seg * NE + (NE - 1)) * n_pad + i] = dend;
     }

@@ -99,9 +99,20 @@ hipError_t KMVP_CAT(KMVP_FN, _generic)(int sig, const real* x, const real* y, co
   const dim3 grid((unsigned)((n_pad / BLOCK_THREADS) * segments));
   if (D <= LOWD_MID_MAX_D) {  // coordinates in registers; x, y and b arrive padded to rows of 8 ceil(. / 8) entries
     if (kernel_name) *kernel_name = "lowd_mid_kernel";
-#define KMVP_MID(SIGV, DCH)                                                                                   \
-  hipLaunchKernelGGL((lowd_mid_kernel<KERNEL, SIGV, real, DCH>), grid, dim3(BLOCK_THREADS), 0, stream, x, y, b, \
-                     part, n, n_pad, m, E, (E + 7) / 8 * 8, NE, segments, seg_len, j_offset, m_total)
+    const int ebw = lowd_mid_colblock((int)sizeof(real), D, E);  // signal columns per pass (the host pads b to it)
+    const int EPm = (E + ebw - 1) / ebw * ebw;
+#define KMVP_MID(SIGV, DCH)                                                                                           \
+  do {                                                                                                                \
+    if constexpr (sizeof(real) == 4 && DCH <= 8) {                                                                    \
+      if (ebw == 32) {                                                                                                \
+        hipLaunchKernelGGL((lowd_mid_kernel<KERNEL, SIGV, real, DCH, 32>), grid, dim3(BLOCK_THREADS), 0, stream, x, y, \
+                           b, part, n, n_pad, m, E, EPm, NE, segments, seg_len, j_offset, m_total);                   \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((lowd_mid_kernel<KERNEL, SIGV, real, DCH, 8>), grid, dim3(BLOCK_THREADS), 0, stream, x, y, b,  \
+                       part, n, n_pad, m, E, EPm, NE, segments, seg_len, j_offset, m_total);                          \
+  } while (0)
 #define KMVP_MID_D(SIGV)                \
   switch ((D + 7) / 8) {                \
     case 1: KMVP_MID(SIGV, 1); break;   \

@@ -388,8 +388,9 @@ int run_product_t(kmvp_ctx* c, int kernel, int sig) {
     if ((rc = ensure(c, c->part, (size_t)segments * NE * n_pad * sizeof(double)))) return rc;
     const real* xg = (const real*)(c->same_points ? c->y_scaled.p : c->x_scaled.p);
     const real* bg = sig == SIG_DENSITY ? nullptr : (const real*)c->b_raw.p;
-    if (sig != SIG_DENSITY) {  // signal rows padded to whole blocks of 8 columns
-      const int EP = (c->E + 7) / 8 * 8;
+    if (sig != SIG_DENSITY) {  // signal rows padded to whole column blocks of the kernel (8, or 32: lowd_mid_colblock)
+      const int cb = D <= LOWD_MID_MAX_D ? lowd_mid_colblock((int)sizeof(real), D, c->E) : 8;
+      const int EP = (c->E + cb - 1) / cb * cb;
       if ((rc = ensure(c, c->rec, (size_t)M * EP * sizeof(real)))) return rc;
       hipLaunchKernelGGL((pad_rows_kernel<real>), dim3(blocks_for(M * EP)), dim3(256), 0, c->stream,
                          (const real*)c->b_raw.p, (real*)c->rec.p, M, c->E, EP);
