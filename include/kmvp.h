@@ -152,7 +152,8 @@ int kmvp_comm_rank(const kmvp_ctx* ctx);
  *   "fast_sqdists"     squared distances in the expanded form |x|^2+|y|^2-2x.y on the matrix
  *                      cores (bruteforce.py:36-49 `fast_sqdists`; float32):
  *                      1 = always, around one centre for the whole cloud: fast_kernel (E == 1, D <= 39); with several
- *                          signal columns, or beyond D = 39 (Gaussian, D <= 64): fastmm_kernel, where the tile of kernel values goes
+ *                          signal columns, or beyond D = 39 (Gaussian, D <= 64; exp(-r) at 5 <= D <= 64 inside the
+ *                          radius rule, closest pairs recomputed exactly): fastmm_kernel, where the tile of kernel values goes
  *                          back to the matrix cores for the product with the signal, up to 32 columns per pass
  *                          (the denominator of normalised rows is one more column);
  *                      2 = always, around per-group centres of Morton-sorted sources with exact

@@ -11,6 +11,8 @@
 //                                                                    that subtracts FMM_SHIFT: T = 2^15 exp(-s));
 //                                                                    D <= 64, KS = ceil((6 D + 7) / 16) <= 25
 //   T  = exp2(-S)                                   16 v_exp_f32 per lane: the one transcendental per PAIR
+//                                                   (exp(-r), KERNEL = K_ABSEXP: exp2(15 - sqrt(S)) without the shift
+//                                                   column, closest pairs recomputed exactly: see the kernel)
 //   T  = T_h + T_l  (two f16: 11 + 11 bits)         v_cvt_pk_f16_f32, v_fma_mix_f32 (T - T_h), v_cvt_pk_f16_f32
 //   O (32 columns x 32 targets) += B'^T T           f16 MFMAs, fp32 accumulators: up to 32 signal columns at once
 //
@@ -69,6 +71,13 @@ struct FastmmArgs {
   int tile_blocks;
   int chunk_stages;
   int NE;                    // columns written (numerators [+ denominator])
+  // exp(-r) only: the caller's coordinates for the exact recomputation of the closest pairs
+  const float* xraw;         // targets (N, D)
+  const float* yraw;         // sources (M, D)
+  int64_t n, m;
+  int D;
+  float scale;               // the kernel's constant, applied AFTER a difference is formed
+  float tau;                 // pairs with s <= tau are recomputed in the difference form
 };
 
 // t - (float)pair[0] and t - (float)pair[1] in ONE instruction each: v_fma_mix_f32 reads an f16 half of a register as
@@ -85,8 +94,16 @@ __device__ __forceinline__ float fmm_minus_hi_half(float t, h16x2 pair) {
   return r;
 }
 
-template <int KS, int MODE, int TT>
+// T = 2^FMM_SHIFT k(s).  Gaussian: the shift rides in the operands (S = s - 15); exp(-r): S = s, one v_sqrt_f32 more.
+template <int KERNEL>
+__device__ __forceinline__ float fmm_tval(float S) {
+  if constexpr (KERNEL == K_GAUSSIAN) return kexp2(-S);
+  else return kexp2((float)FMM_SHIFT - __builtin_amdgcn_sqrtf(__builtin_fabsf(S)));
+}
+
+template <int KS, int MODE, int TT, int KERNEL = K_GAUSSIAN>
 __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs a) {
+  static_assert(KERNEL == K_GAUSSIAN || KERNEL == K_ABSEXP, "bounded kernels only");
   constexpr int RB = fmm_row_bytes(KS);
   constexpr int TB = fmm_tile_bytes(KS, MODE);
   constexpr int SB = fmm_stage_bytes(KS, MODE);
@@ -195,13 +212,40 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
       if (q + 1 < ST) distances(q + 1, dn);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-        const f32x16 d = dc[tt];
+        f32x16 d = dc[tt];
+        if constexpr (KERNEL == K_ABSEXP) {
+          // exp(-r) hinges on the RELATIVE accuracy of small s, the expansion around one centre has an absolute error
+          // ~1e-7 R^2: pairs with s <= tau = kappa R^4 (the host's bound; in practice coincident and nearly coincident
+          // points) are recomputed in the difference form from the caller's coordinates -- a wave-uniform rare branch
+          float dmin = fminf(fminf(d[0], d[1]), d[2]);
+#pragma unroll
+          for (int qq = 3; qq < 15; qq += 2) dmin = fminf(fminf(dmin, d[qq]), d[qq + 1]);
+          dmin = fminf(dmin, d[15]);
+          if (__any(!(dmin > a.tau))) {
+            const int64_t it = (tile0 + tt) * FAST_TILE + r;
+            const int64_t j0 = (s * ST + q) * FAST_TILE;
+#pragma unroll
+            for (int qq = 0; qq < 16; ++qq) {
+              const int64_t j = j0 + acc_row(qq, h);
+              if (!(d[qq] > a.tau) && it < a.n && j < a.m) {
+                const float* xr = a.xraw + it * a.D;
+                const float* yr = a.yraw + j * a.D;
+                float sx = 0.f;
+                for (int c = 0; c < a.D; ++c) {
+                  const float e = (xr[c] - yr[c]) * a.scale;
+                  sx = fmaf(e, e, sx);
+                }
+                d[qq] = sx;
+              }
+            }
+          }
+        }
         h16x8 th[2], tl[2];
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const fmm_f32x2 t = {kexp2(-d[8 * g2 + 2 * i]), kexp2(-d[8 * g2 + 2 * i + 1])};
+            const fmm_f32x2 t = {fmm_tval<KERNEL>(d[8 * g2 + 2 * i]), fmm_tval<KERNEL>(d[8 * g2 + 2 * i + 1])};
             const h16x2 hh = __builtin_convertvector(t, h16x2);
             const fmm_f32x2 rest = {fmm_minus_lo_half(t[0], hh), fmm_minus_hi_half(t[1], hh)};
             const h16x2 ll = __builtin_convertvector(rest, h16x2);

@@ -1,18 +1,23 @@
 // Instantiations of fastmm_kernel (kmvp_fastmm.hpp): KS = k-steps of the squared-distance product (point dimension D:
 // KS = ceil((6 D + 7) / 16), D <= 64), MODE = 0 (<= 16 columns) / 1 (<= 32), TT = target tiles of 32 per wave (two while
 // KS <= 4).
+// Compiled twice: -DKMVP_FMM_KERNEL=0 -DKMVP_FN=launch_fastmm_gaussian, -DKMVP_FMM_KERNEL=1 -DKMVP_FN=launch_fastmm_absexp.
 #include "kmvp_internal.hpp"
 #include "kmvp_fastmm.hpp"
 
+#ifndef KMVP_FMM_KERNEL
+#error "KMVP_FMM_KERNEL and KMVP_FN must be defined"
+#endif
+
 namespace kmvp {
 
-template <int KS, int MODE>
+template <int KS, int MODE, int KERNEL>
 static hipError_t launch_tt(int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
   switch (TT) {
-    case 1: hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
+    case 1: hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 1, KERNEL>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
     case 2:
       if constexpr (KS <= FMM_MAX_KS_TWO_TILES) {
-        hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+        hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 2, KERNEL>), grid, dim3(BLOCK_THREADS), 0, stream, args);
         break;
       }
       return hipErrorInvalidValue;
@@ -23,11 +28,12 @@ static hipError_t launch_tt(int TT, const FastmmArgs& args, dim3 grid, hipStream
 
 template <int KS>
 static hipError_t launch_mode(int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
-  return mode ? launch_tt<KS, 1>(TT, args, grid, stream) : launch_tt<KS, 0>(TT, args, grid, stream);
+  return mode ? launch_tt<KS, 1, KMVP_FMM_KERNEL>(TT, args, grid, stream)
+              : launch_tt<KS, 0, KMVP_FMM_KERNEL>(TT, args, grid, stream);
 }
 
-hipError_t launch_fastmm_gaussian(int KS, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
-                                  const char** kernel_name) {
+hipError_t KMVP_FN(int KS, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
+                   const char** kernel_name) {
   if (kernel_name) *kernel_name = "fastmm_kernel";
   switch (KS) {
     case 1: return launch_mode<1>(mode, TT, args, grid, stream);

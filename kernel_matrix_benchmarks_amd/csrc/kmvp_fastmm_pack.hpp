@@ -50,9 +50,10 @@ __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float
 // (j = 0 .. 7) of target 32 t + r's augmented row -- per d (x_h, x_m, x_h, x_l, x_m, x_h) of the centred scaled coordinate
 // split three ways into bf16, then 1, 1, 1, |x'|^2 h, m, l (accumulated in double, rounded once), -FMM_SHIFT, zeros.
 // One thread per (target, k-step, lane half).
+// (shift: FMM_SHIFT for the Gaussian, 0 for exp(-r), whose shift is applied after the square root)
 __global__ void pack_fastmm_targets_kernel(const float* __restrict__ x, const float* __restrict__ centre,
                                            unsigned char* __restrict__ xop, int64_t n, int64_t n_pad, int D, int KS,
-                                           float scale) {
+                                           float scale, float shift) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= n_pad * KS * 2) return;
   const int64_t i = id / (2 * KS);
@@ -83,7 +84,7 @@ __global__ void pack_fastmm_targets_kernel(const float* __restrict__ x, const fl
     } else if (k == 6 * D + 5) {
       e = sl;
     } else if (k == 6 * D + 6) {
-      e = (__bf16)(-(float)FMM_SHIFT);
+      e = (__bf16)(-shift);
     }
     out[j] = e;
   }

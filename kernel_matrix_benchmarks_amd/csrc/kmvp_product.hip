@@ -574,7 +574,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
 
 // Gaussian products with several signal columns, both matrix products on the matrix cores (kmvp_fastmm.hpp): float32,
 // D <= 64, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
-int run_product_fastmm(kmvp_ctx* c, int sig) {
+int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
   const int D = c->D, E = c->E;
   const int NE = sig == SIG_NORM ? E + 1 : E;
   const int64_t N = c->N, M = c->M;
@@ -584,7 +584,7 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   const int tt_max = KS <= FMM_MAX_KS_TWO_TILES ? 2 : 1;  // (four tiles: no faster, 256 VGPRs)
   const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, tt_max) : (small ? 1 : tt_max);
   const int64_t SB = fmm_stage_bytes(KS, MODE);
-  const float scale = scale_for<float>(K_GAUSSIAN);
+  const float scale = scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   const int64_t tile = (int64_t)FAST_TILE * TT * WAVES_PER_BLOCK;
   const int64_t n_pad = round_up(N, tile);
@@ -602,7 +602,7 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   if (tile_blocks * segments > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
 
   const int layout_T = TT + 16 * MODE;
-  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != K_GAUSSIAN ||
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
                          c->packed_layout != LAYOUT_FASTMM || c->packed_T != layout_T;
   const bool one_block = NE <= FMM_MAX_COLS;
   const bool sig_stale = pts_stale || !one_block || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
@@ -614,14 +614,15 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
     if ((rc = ensure(c, c->xs, (size_t)n_pad * KS * 32))) return rc;
     if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
     hipLaunchKernelGGL(pack_fastmm_targets_kernel, dim3(blocks_for(n_pad * KS * 2)), dim3(256), 0, c->stream, x_raw,
-                       centre, (unsigned char*)c->xs.p, N, n_pad, D, KS, scale);
+                       centre, (unsigned char*)c->xs.p, N, n_pad, D, KS, scale,
+                       kernel == K_GAUSSIAN ? (float)FMM_SHIFT : 0.f);
     hipLaunchKernelGGL(pack_fastmm_rows_kernel, dim3(blocks_for(m_stages * fmm_stage_tiles(KS) * FAST_TILE)), dim3(256), 0,
                        c->stream, (const float*)c->y_raw.p, centre, (unsigned char*)c->rec.p, M, m_stages, D, KS, MODE,
                        scale);
     HIP_TRY(c, hipGetLastError());
   }
   c->packed_points_ver = c->points_ver;
-  c->packed_kernel = K_GAUSSIAN;
+  c->packed_kernel = kernel;
   c->packed_layout = LAYOUT_FASTMM;
   c->packed_T = layout_T;
   c->packed_signal_ver = c->signal_ver;
@@ -640,6 +641,16 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
   a.segments = segments;
   a.tile_blocks = (int)tile_blocks;
   a.chunk_stages = std::max(1, 2 * c->opt_chunk / (FAST_TILE * fmm_stage_tiles(KS)));
+  a.xraw = x_raw;
+  a.yraw = (const float*)c->y_raw.p;
+  a.n = N;
+  a.m = M;
+  a.D = D;
+  a.scale = scale;
+  {
+    const float r2 = c->cloud_radius2 * scale * scale;  // scaled squared radius of the clouds
+    a.tau = kernel == K_ABSEXP ? FMM_ABSEXP_KAPPA * r2 * r2 : 0.f;
+  }
   const dim3 grid((unsigned)(tile_blocks * segments));
   const int64_t pieces = m_stages * fmm_stage_tiles(KS) * (MODE ? 2 : 1) * 2 * 64;
   HIP_TRY(c, mark(c, 0));
@@ -654,7 +665,8 @@ int run_product_fastmm(kmvp_ctx* c, int sig) {
       HIP_TRY(c, hipGetLastError());
     }
     a.NE = nb;
-    hipError_t le = launch_fastmm_gaussian(KS, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
+    hipError_t le = kernel == K_ABSEXP ? launch_fastmm_absexp(KS, MODE, TT, a, grid, c->stream, &c->last_kernel_name)
+                                       : launch_fastmm_gaussian(KS, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
     if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "no fastmm_kernel for this dimension / tile count");
     HIP_TRY(c, le);
     if (!one_block) {
@@ -1743,12 +1755,25 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       const double t_fmm = tiles * ((cols + FMM_MAX_COLS - 1) / FMM_MAX_COLS) * (cols > 16 ? FMM_PS_PER_TILE_32 : FMM_PS_PER_TILE_16);
       if (c->opt_fast == 1 || t_fmm <= t_cell) {
         c->note.clear();
-        return run_product_fastmm(c, sig);
+        return run_product_fastmm(c, K_GAUSSIAN, sig);
       }
     }
     if (t_cell < INFINITY) {
       c->note.clear();
       return run_product_cellmm(c, sig);
+    }
+  }
+  if (c->dtype == KMVP_F32 && kernel == K_ABSEXP && !c->density && c->D > CFAST_MAX_D && c->D <= FMM_MAX_D &&
+      c->centre_ver == c->points_ver && (c->opt_fast < 0 || c->opt_fast == 1)) {
+    // exp(-r) beyond the centred forms' D = 4: fastmm_kernel's expansion around one centre with the closest pairs
+    // recomputed exactly (any number of signal columns, one included), on clouds inside the radius rule
+    // (auto: beyond the specialised difference form's D = 8, or where that form would go column by column -- at
+    // D = 5 with up to four columns the two are equally fast)
+    const float sc = scale_for<float>(kernel);
+    const bool pays = c->D > LOWD_MAX_D || c->E + (normalise ? 1 : 0) > LOWD_MAX_E;
+    if (c->cloud_radius2 * sc * sc <= FAST_AUTO_RADIUS2 && (c->opt_fast == 1 || pays)) {
+      c->note.clear();
+      return run_product_fastmm(c, K_ABSEXP, sig);
     }
   }
   if (c->dtype == KMVP_F32 && (kernel == K_GAUSSIAN || kernel == K_ABSEXP) && !c->density && c->E > 1 &&

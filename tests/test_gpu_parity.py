@@ -190,8 +190,10 @@ def test_fast_sqdists_matches_reference(case, expected):
         pytest.skip("coincident points: the expansion has no exact zero distance")
     got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists=True)
     if not (case["normalize_rows"] and case["density_estimation"]):
-        assert extra["device_kernel"] == "fast_kernel"
-    if case["kernel"] == "gaussian":
+        # (exp(-r) at 5 <= D <= 64 inside the radius rule: the same expansion with the closest pairs recomputed exactly --
+        # fastmm_kernel, held to the Gaussian's tolerance)
+        assert extra["device_kernel"] in ("fast_kernel", "fastmm_kernel")
+    if case["kernel"] == "gaussian" or extra.get("device_kernel") == "fastmm_kernel":
         tol = TOL32
     else:
         # not smooth at s = 0: the absolute error of the expanded s is amplified near coincident
@@ -370,6 +372,65 @@ def test_cfastmm_kernel_near_pairs_column_blocks_and_wide_clouds(kernel, D, E, n
                                 precision=np.float32)
     assert got.shape == (n, E)
     assert rel_err(got, want) <= max(TOL32, 2 * rel_err(ref32, want)), (rel_err(got, want), rel_err(ref32, want))
+
+
+FMM_ABSEXP = [c for c in CASES if 5 <= c["D"] <= 64 and c["kernel"] == "absolute-exponential" and not c["density_estimation"]]
+
+
+@pytest.mark.parametrize("case", FMM_ABSEXP, ids=[c["name"] for c in FMM_ABSEXP])
+def test_fastmm_kernel_for_exp_of_minus_r_matches_reference(case, expected):
+    """exp(-r) at 5 <= D <= 64 (one or many signal columns) on fastmm_kernel: the expansion around one centre with the
+    closest pairs recomputed in the difference form (fast_sqdists=True forces it; auto takes it beyond D = 8 or four
+    columns) -- held to the tolerance of the difference form."""
+    y, x, b = golden_cases.make_inputs(case)
+    truth = expected[f"{case['name']}/f64"]
+    ref32 = expected[f"{case['name']}/f32"].astype(np.float64)
+    results = []
+    for tiles in (1, 2):
+        got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists=True, fast_tiles=tiles)
+        if extra["device_kernel"] == "fast_kernel":
+            return  # clouds outside the radius rule: the forced flag means the reference's plain expanded form there
+        assert extra["device_kernel"] == "fastmm_kernel", extra
+        tol = max(TOL32, 2 * rel_err(ref32, truth))
+        assert got.shape == truth.shape and rel_err(got, truth) <= tol, (tiles, rel_err(got, truth), tol)
+        results.append(got)
+    assert np.array_equal(results[0], results[1])
+
+
+@pytest.mark.parametrize("D,E,norm", [(8, 5, True), (16, 1, False), (16, 20, True), (33, 3, False), (64, 40, True)])
+def test_fastmm_exp_of_minus_r_with_coincident_and_nearly_coincident_pairs(D, E, norm):
+    """The exact branch: targets that coincide with sources, or sit a few float32 ulps from them, inside an otherwise
+    ordinary cloud (exp(-r) has a kink at r = 0: the one-centre expansion alone would be off by ~5e-4 on such a pair),
+    ragged sizes, auto dispatch.  Against the float64 oracle on the float32-rounded inputs."""
+    rng = np.random.RandomState(3 * D + E)
+    n, m = 1171, 1999
+    y = (rng.rand(m, D) / np.sqrt(D / 3.0)).astype(np.float32).astype(np.float64)
+    x = (rng.rand(n, D) / np.sqrt(D / 3.0)).astype(np.float32).astype(np.float64)
+    x[:300] = y[:300]
+    x[300:500] = (y[300:500] * (1.0 + 3e-7)).astype(np.float32).astype(np.float64)
+    # few neighbours, large weights on the coincident sources: the near pairs dominate their rows
+    b = rng.randn(m, E).astype(np.float32).astype(np.float64)
+    b[:500] *= 50.0
+    algo = MI355XProduct(kernel="absolute-exponential", dimension=D, normalize_rows=norm, precision="float32")
+    try:
+        algo.prepare_data(source_points=y, target_points=x)
+        algo.fit()
+        algo.prepare_query(source_signal=b)
+        algo.query()
+        got = algo.get_result()
+        assert algo.device_kernel == "fastmm_kernel", algo.device_kernel
+    finally:
+        algo.done()
+    want = kmvp_oracle.product(kernel="absolute-exponential", source_points=y, target_points=x, source_signal=b,
+                               normalize_rows=norm)
+    ref32 = kmvp_oracle.product(kernel="absolute-exponential", source_points=y, target_points=x, source_signal=b,
+                                normalize_rows=norm, precision=np.float32)
+    assert got.shape == (n, E)
+    assert rel_err(got, want) <= max(TOL32, 2 * rel_err(ref32, want)), (rel_err(got, want), rel_err(ref32, want))
+    # row by row on the rows of the near pairs (a relative error of 5e-4 on one dominant term would show here)
+    rows = np.arange(500)
+    row_err = np.abs(got[rows] - want[rows]).max(axis=1) / np.abs(want[rows]).max(axis=1)
+    assert row_err.max() <= 2e-5, row_err.max()
 
 
 def test_auto_choice_between_fastmm_and_cellmm():
