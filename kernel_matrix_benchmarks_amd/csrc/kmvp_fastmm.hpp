@@ -101,6 +101,18 @@ __device__ __forceinline__ float fmm_tval(float S) {
   else return kexp2((float)FMM_SHIFT - __builtin_amdgcn_sqrtf(__builtin_fabsf(S)));
 }
 
+// the difference form of one pair from the caller's coordinates (rare branch of the exp(-r) variant; kept out of line:
+// sixteen inlined copies of the loop cost the hot path registers)
+__device__ __attribute__((noinline)) float fmm_exact_sqdist(const float* __restrict__ xr, const float* __restrict__ yr,
+                                                             int D, float scale) {
+  float sx = 0.f;
+  for (int c = 0; c < D; ++c) {
+    const float e = (xr[c] - yr[c]) * scale;
+    sx = fmaf(e, e, sx);
+  }
+  return sx;
+}
+
 template <int KS, int MODE, int TT, int KERNEL = K_GAUSSIAN>
 __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs a) {
   static_assert(KERNEL == K_GAUSSIAN || KERNEL == K_ABSEXP, "bounded kernels only");
@@ -227,16 +239,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
 #pragma unroll
             for (int qq = 0; qq < 16; ++qq) {
               const int64_t j = j0 + acc_row(qq, h);
-              if (!(d[qq] > a.tau) && it < a.n && j < a.m) {
-                const float* xr = a.xraw + it * a.D;
-                const float* yr = a.yraw + j * a.D;
-                float sx = 0.f;
-                for (int c = 0; c < a.D; ++c) {
-                  const float e = (xr[c] - yr[c]) * a.scale;
-                  sx = fmaf(e, e, sx);
-                }
-                d[qq] = sx;
-              }
+              if (!(d[qq] > a.tau) && it < a.n && j < a.m) d[qq] = fmm_exact_sqdist(a.xraw + it * a.D, a.yraw + j * a.D, a.D, a.scale);
             }
           }
         }
