@@ -142,6 +142,15 @@ int kmvp_comm_init(kmvp_ctx* ctx, const void* id128, int rank, int world);
  * N ranks. */
 int kmvp_comm_world(const kmvp_ctx* ctx);
 int kmvp_comm_rank(const kmvp_ctx* ctx);
+/* REHEARSAL transport for the same exchange (not the product: RCCL is).  RCCL refuses two ranks on one device,
+ * so the multi-rank path of this library -- shard-local kernels with j_offset / M_total, the canonical unpadded
+ * [column][N] layout, exchange, normalisation, the sharded solvers -- cannot be exercised with world > 1 on a
+ * one-GPU box through kmvp_comm_init.  With this entry the all-reduce is staged through host memory instead:
+ * `fn(user, buf, count)` must sum `count` doubles in place over all ranks (e.g. torch.distributed.all_reduce
+ * over gloo) and return 0.  Everything else -- what is exchanged, where in the stream, what happens before and
+ * after -- is the code path kmvp_comm_init uses.  Never selected implicitly. */
+typedef int (*kmvp_host_allreduce_fn)(void* user, double* buf, int64_t count);
+int kmvp_comm_init_host(kmvp_ctx* ctx, kmvp_host_allreduce_fn fn, void* user, int rank, int world);
 
 /* BaseAlgorithm.set_query_arguments (base.py:40-42): tuning knobs, all optional.
  *   "feed"             -1 = auto (default), 0 = scalar-cache source stream, 1 = LDS-staged tiles

@@ -44,6 +44,7 @@ SYMBOLS = [
                                              _c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
     ("kmvp_comm_get_unique_id", _c.c_int, [_c.c_void_p]),
     ("kmvp_comm_init", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
+    ("kmvp_comm_init_host", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int]),
     ("kmvp_comm_world", _c.c_int, [_c.c_void_p]),
     ("kmvp_comm_rank", _c.c_int, [_c.c_void_p]),
     ("kmvp_last_allreduce_ms", _c.c_double, [_c.c_void_p]),
@@ -54,6 +55,8 @@ SYMBOLS = [
     ("kmvp_last_kernel_name", _c.c_char_p, [_c.c_void_p]),
     ("kmvp_last_dispatch_note", _c.c_char_p, [_c.c_void_p]),
 ]
+
+HOST_ALLREDUCE_FN = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.POINTER(_c.c_double), _c.c_int64)
 
 _lib = None
 
@@ -199,9 +202,26 @@ class Context:
         self._check(self._lib.kmvp_comm_init(self._ctx, buf, int(rank), int(world)))
         self.comm_world = int(world)  # attachment is recorded on the context itself (sharding.Communicator.attach)
 
+    def comm_init_host(self, allreduce, rank, world):
+        """REHEARSAL transport (include/kmvp.h kmvp_comm_init_host): ``allreduce(array)`` must sum a float64 numpy
+        array in place over all ranks.  The library stages the exchange buffer through host memory and calls it."""
+
+        def trampoline(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
+                return 0
+            except Exception as e:  # never let a Python exception cross the C frame
+                self._host_error = e
+                return 1
+
+        self._host_cb = HOST_ALLREDUCE_FN(trampoline)  # kept alive as long as the context
+        self._check(self._lib.kmvp_comm_init_host(self._ctx, ctypes.cast(self._host_cb, ctypes.c_void_p), None,
+                                                  int(rank), int(world)))
+        self.comm_world = int(world)
+
     @property
     def rccl_ranks(self):
-        """Ranks the attached RCCL communicator itself reports (1 without one)."""
+        """Ranks the attached communicator itself reports (1 without one)."""
         return int(self._lib.kmvp_comm_world(self._ctx))
 
     @property

@@ -382,26 +382,43 @@ class MI355XSolver(BaseSolver):
         self.iterations, self.outer_iterations, self.converged = 0, 0, False
         rel = float(np.max(np.linalg.norm(r, axis=0) / anorm))
         best = rel
+        # why the outer loop ended (get_additional "refinement_stop_reason"): tolerance | stagnation | maxit |
+        # outer-limit | non-finite; with the last inner solve's own verdict beside it, so that a stalled refinement
+        # (inner solve converged, outer residual stuck) can be told from an exhausted iteration budget
+        self.stop_reason, self.inner_residual, self.inner_converged = "outer-limit", float("nan"), None
         for _ in range(40):
-            if rel <= self.rtol or self.iterations >= self.maxit:
+            if rel <= self.rtol:
+                self.stop_reason = "tolerance"
+                break
+            if self.iterations >= self.maxit:
+                self.stop_reason = "maxit"
                 break
             scale = np.max(np.abs(r), axis=0)
             scale[scale == 0] = 1.0  # (a power-of-two free scaling is not needed: float32 has the range, this keeps it centred)
-            d, iters, _, _ = self._ctx32.cg_solve(self._device_kernel_fn, np.ascontiguousarray(r / scale, dtype=np.float32),
-                                                 self.inner_rtol, max(1, self.maxit - self.iterations))
+            d, iters, inner_res, inner_ok = self._ctx32.cg_solve(
+                self._device_kernel_fn, np.ascontiguousarray(r / scale, dtype=np.float32), self.inner_rtol,
+                max(1, self.maxit - self.iterations))
             self.iterations += iters
             self.outer_iterations += 1
+            self.inner_residual, self.inner_converged = float(inner_res), bool(inner_ok)
             x_new = x + d * scale
             self._ctx.set_signal(x_new)
             self._ctx.run(self._device_kernel_fn, False)
             r_new = a - self._ctx.get_result(self.M, a.shape[1])
             rel_new = float(np.max(np.linalg.norm(r_new, axis=0) / anorm))
-            if not np.isfinite(rel_new) or rel_new > 0.9 * best:
+            if not np.isfinite(rel_new):
+                self.stop_reason = "non-finite"
+                break
+            if rel_new > 0.9 * best:
                 # the float32 correction did not help (inner tolerance beyond what a float32 operator can reach on
                 # this matrix): keep the last good iterate and say so through `converged`
+                self.stop_reason = "stagnation"
                 break
             x, r, rel = x_new, r_new, rel_new
             best = rel
+        else:
+            if rel <= self.rtol:
+                self.stop_reason = "tolerance"
         self.res, self.residual = x, rel
         self.converged = bool(np.isfinite(rel) and rel <= 1.5 * self.rtol)
 
@@ -417,6 +434,9 @@ class MI355XSolver(BaseSolver):
         if self.refine and self._ctx32 is not None:
             extra["refinement_steps"] = self.outer_iterations
             extra["inner_device_kernel"] = self._ctx32.last_kernel_name
+            extra["refinement_stop_reason"] = getattr(self, "stop_reason", "")
+            extra["refinement_last_inner_residual"] = getattr(self, "inner_residual", float("nan"))
+            extra["refinement_last_inner_converged"] = bool(getattr(self, "inner_converged", False))
         return extra
 
     def done(self):

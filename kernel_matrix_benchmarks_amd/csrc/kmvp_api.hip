@@ -215,6 +215,8 @@ int kmvp_comm_init(kmvp_ctx* c, const void* id128, int rank, int world) {
     g_rccl.CommDestroy(c->comm);
     c->comm = nullptr;
   }
+  c->host_xchg = nullptr;
+  c->host_user = nullptr;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
@@ -245,8 +247,22 @@ int kmvp_comm_init(kmvp_ctx* c, const void* id128, int rank, int world) {
   return KMVP_OK;
 }
 
-int kmvp_comm_world(const kmvp_ctx* c) { return (c && c->comm) ? c->comm_count : 1; }
-int kmvp_comm_rank(const kmvp_ctx* c) { return (c && c->comm) ? c->rank : 0; }
+int kmvp_comm_init_host(kmvp_ctx* c, kmvp_host_allreduce_fn fn, void* user, int rank, int world) {
+  if (!c || !fn || world < 1 || rank < 0 || rank >= world) return fail(c, KMVP_E_INVALID, "bad communicator arguments");
+  if (c->comm) {
+    g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
+  c->host_xchg = fn;
+  c->host_user = user;
+  c->comm_count = world;
+  c->rank = rank;
+  c->world = world;
+  return KMVP_OK;
+}
+
+int kmvp_comm_world(const kmvp_ctx* c) { return (c && c->exchanges()) ? c->comm_count : 1; }
+int kmvp_comm_rank(const kmvp_ctx* c) { return (c && c->exchanges()) ? c->rank : 0; }
 
 int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
   if (!c || !key) return KMVP_E_INVALID;

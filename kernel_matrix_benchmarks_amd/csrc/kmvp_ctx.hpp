@@ -150,6 +150,11 @@ struct kmvp_ctx {
   // sharding
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  // rehearsal transport (kmvp_comm_init_host): the same exchange staged through host memory and summed by a callback
+  kmvp_host_allreduce_fn host_xchg = nullptr;
+  void* host_user = nullptr;
+  std::vector<double> host_buf;
+  bool exchanges() const { return comm != nullptr || host_xchg != nullptr; }
 
   int comm_count = 1;                      // ranks the RCCL communicator itself reports (ncclCommCount)
   float last_kernel_ms = 0.f, last_total_ms = 0.f, last_allreduce_ms = 0.f;

@@ -183,7 +183,7 @@ inline hipError_t mark(kmvp_ctx* c, int i) { return c->async_product ? hipSucces
 int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, int sig) {
   int rc;
   const double* sums = (const double*)c->sums.p;
-  if (c->comm) {  // also with world == 1: the one-GPU tests then run the real exchange path
+  if (c->exchanges()) {  // also with world == 1: the one-GPU tests then run the real exchange path
     // The padded length n_pad belongs to the kernel a rank happened to choose (tile sizes differ
     // between the paths, and the auto policy looks at the rank's own clouds), so the exchange uses
     // the canonical unpadded layout [column][N]: every rank contributes exactly NE * N doubles.
@@ -193,10 +193,22 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
                        N, n_pad, NE);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, mark(c, 3));
-    ncclResult_t r = g_rccl.AllReduce(c->xchg.p, c->xchg.p, (size_t)(NE * N), ncclFloat64, ncclSum, c->comm,
-                                      c->stream);
-    if (r != ncclSuccess)
-      return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    if (c->comm) {
+      ncclResult_t r = g_rccl.AllReduce(c->xchg.p, c->xchg.p, (size_t)(NE * N), ncclFloat64, ncclSum, c->comm,
+                                        c->stream);
+      if (r != ncclSuccess)
+        return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    } else {
+      // rehearsal transport: device -> host, the caller's all-reduce (e.g. gloo), host -> device.  Same buffer, same
+      // canonical layout, same place in the stream as the RCCL call -- only the wire differs.
+      const size_t cnt = (size_t)(NE * N);
+      c->host_buf.resize(std::max<size_t>(cnt, 1));
+      HIP_TRY(c, hipMemcpyAsync(c->host_buf.data(), c->xchg.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      const int hr = c->host_xchg(c->host_user, c->host_buf.data(), (int64_t)cnt);
+      if (hr != 0) return fail(c, KMVP_E_COMM, "host all-reduce callback failed with status " + std::to_string(hr));
+      HIP_TRY(c, hipMemcpyAsync(c->xchg.p, c->host_buf.data(), cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, mark(c, 4));
     sums = (const double*)c->xchg.p;
     n_pad = N;
@@ -213,7 +225,7 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
   HIP_TRY(c, hipEventElapsedTime(&c->last_kernel_ms, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]));
   c->last_allreduce_ms = 0.f;
-  if (c->comm) HIP_TRY(c, hipEventElapsedTime(&c->last_allreduce_ms, c->ev[3], c->ev[4]));
+  if (c->exchanges()) HIP_TRY(c, hipEventElapsedTime(&c->last_allreduce_ms, c->ev[3], c->ev[4]));
   return KMVP_OK;
 }
 
@@ -224,7 +236,7 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
 int reduce_and_finish(kmvp_ctx* c, int segments, int NE, int64_t N, int64_t n_pad, int E, int sig) {
   int rc;
   const int64_t count = (int64_t)NE * n_pad;
-  if (c->comm) {
+  if (c->exchanges()) {
     if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
     hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
                        (const double*)c->part.p, (double*)c->sums.p, count, segments);
@@ -1672,13 +1684,13 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   if (!c->have_points) return fail(c, KMVP_E_INVALID, "kmvp_set_points has not been called");
   if (!c->have_signal) return fail(c, KMVP_E_INVALID, "kmvp_set_signal has not been called");
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->M < c->m_total && !(c->comm && c->world > 1) && !c->opt_partial)
+  if (c->M < c->m_total && !(c->exchanges() && c->world > 1) && !c->opt_partial)
     // a slice of the sources and nobody to sum the shards with: the result would be this rank's partial
     // sums passed off as the product
     return fail(c, KMVP_E_INVALID,
                 "the sources are a shard (M < M_total) but no multi-rank communicator is attached: call kmvp_comm_init, "
                 "or set option partial_shard = 1 to get this shard's partial sums on purpose");
-  if (c->M == 0 && c->N > 0 && c->comm && c->world > 1) {
+  if (c->M == 0 && c->N > 0 && c->exchanges() && c->world > 1) {
     // a rank whose source slice is empty still owes the other ranks its (zero) share of the sums
     const int sig0 = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
     const int E = c->density ? 1 : c->E;

@@ -18,7 +18,7 @@ constexpr int CG_BLOCKS = 256;
 // (same_points_global, N == M_total), and a communicator is attached.
 static int solver_shape(kmvp_ctx* c) {
   if (c->same_points && c->world == 1) return KMVP_OK;
-  if (c->world > 1 && !c->comm) return fail(c, KMVP_E_INVALID, "sharded solver without kmvp_comm_init");
+  if (c->world > 1 && !c->exchanges()) return fail(c, KMVP_E_INVALID, "sharded solver without kmvp_comm_init");
   const bool sharded_square = c->opt_same_global && c->N == c->m_total && c->j_offset + c->M <= c->m_total &&
                              (c->world > 1 || c->M == c->m_total);  // one rank must hold every source
   if (c->same_points && c->world > 1)
@@ -295,7 +295,7 @@ int cg_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol, in
     return KMVP_OK;
   };
   hipGraphExec_t gexec = nullptr;
-  bool try_graph = c->comm == nullptr && getenv("KMVP_NO_GRAPH") == nullptr;
+  bool try_graph = !c->exchanges() && getenv("KMVP_NO_GRAPH") == nullptr;
   int full_bursts = 0;
   double true_rel = NAN, prev_true = INFINITY;
   // The iteration stops on the RECURRENCE residual; the verdict is on the TRUE one, a - K x, from one more

@@ -75,10 +75,14 @@ class Communicator:
     MPI bcast); it is only used to distribute the RCCL unique id.
     """
 
-    def __init__(self, rank, world, broadcast_bytes):
+    def __init__(self, rank, world, broadcast_bytes, host_allreduce=None):
         self.rank = int(rank)
         self.world = int(world)
         self._broadcast = broadcast_bytes
+        # REHEARSAL only (several ranks on ONE GPU, where RCCL refuses to form a communicator): a callable that sums
+        # a float64 numpy array in place over the ranks; the library then stages its exchange through host memory
+        # (include/kmvp.h kmvp_comm_init_host) instead of calling ncclAllReduce
+        self._host_allreduce = host_allreduce
 
     def attach(self, ctx):
         """Collective: every rank calls it for its context.  Whether a context already has its communicator
@@ -89,6 +93,9 @@ class Communicator:
 
         if self.world == 1 or getattr(ctx, "comm_world", 0) == self.world:
             return
+        if self._host_allreduce is not None:
+            ctx.comm_init_host(self._host_allreduce, self.rank, self.world)
+            return
         uid = _lib.comm_unique_id() if self.rank == 0 else None
         uid = self._broadcast(uid)
         ctx.comm_init(uid, self.rank, self.world)
@@ -96,9 +103,11 @@ class Communicator:
             ctx.comm_world = self.world
 
 
-def torch_gloo_communicator():
+def torch_gloo_communicator(exchange="rccl"):
     """Communicator over an initialised ``torch.distributed`` process group (any
-    backend that can broadcast Python objects from the host, i.e. gloo)."""
+    backend that can broadcast Python objects from the host, i.e. gloo).  The group only carries the RCCL
+    unique id; the sums travel over RCCL inside the library.  ``exchange="host"`` (rehearsal on a one-GPU
+    box): the sums are staged through host memory and summed by this group instead."""
     import torch.distributed as dist
 
     def bcast(payload):
@@ -106,4 +115,13 @@ def torch_gloo_communicator():
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
-    return Communicator(dist.get_rank(), dist.get_world_size(), bcast)
+    host = None
+    if exchange == "host":
+        import torch
+
+        def host(array):
+            dist.all_reduce(torch.from_numpy(array))  # in place, float64, sum
+
+    elif exchange != "rccl":
+        raise ValueError("exchange must be 'rccl' or 'host'")
+    return Communicator(dist.get_rank(), dist.get_world_size(), bcast, host_allreduce=host)

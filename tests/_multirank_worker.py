@@ -1,0 +1,104 @@
+"""One rank of tests/test_gpu_multirank.py (started with RANK / WORLD_SIZE / MASTER_* in the environment).
+
+Every rank drives the PLUGIN (MI355XProduct / MI355XSolver) on GPU 0 with the sources sharded over the ranks, through
+the real libkmvp.so: shard-local pair loops with j_offset / M_total, the canonical unpadded exchange layout, the
+all-reduce, normalisation, the sharded solvers.  The one thing that differs from a multi-GPU run is the wire: RCCL
+refuses two ranks on one device, so the exchange is staged through host memory and summed by gloo
+(include/kmvp.h kmvp_comm_init_host) -- test infrastructure, selected explicitly.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (HERE, os.path.join(HERE, "..", "oracle"), os.path.join(HERE, "..")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    from kernel_matrix_benchmarks_amd import _lib, sharding
+
+    _lib.load()  # the system ROCm stack first (bench.py does the same)
+    import torch.distributed as dist
+
+    import kmvp_oracle
+    from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct, MI355XSolver
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    comm = sharding.torch_gloo_communicator(exchange="host")
+    report = []
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+    # (kernel, normalize, precision, n, D, E, x != y, tolerance)
+    products = [
+        ("gaussian", False, "float32", 40000, 3, 1, False, 1e-5),          # cell order sharding, cell form per rank
+        ("gaussian", True, "float32", 5000, 3, 5, True, 1e-5),             # several columns + denominator column
+        ("inverse-distance", False, "float32", 20000, 3, 1, False, 2e-5),  # global zero rule, centred form (same_points_global)
+        ("inverse-distance", True, np.float64, 3001, 2, 2, False, 1e-11),  # odd split, difference form fp64
+        ("absolute-exponential", True, np.float64, 3000, 5, 3, True, 1e-11),
+        ("absolute-exponential", True, "bfloat16", 4096, 64, 64, False, 1e-2),
+        ("gaussian", False, "float32", world - 1, 3, 1, False, 1e-5),     # fewer sources than ranks: an EMPTY shard
+    ]
+    for kernel, normalize, precision, n, D, E, other, tol in products:
+        rs = np.random.RandomState(n + D)
+        y = rs.rand(n, D) / (np.sqrt(D) if D > 8 else 1.0)
+        b = rs.randn(n, E)
+        x = rs.rand(n // 2 + 3, D) / (np.sqrt(D) if D > 8 else 1.0) if other else None
+        algo = MI355XProduct(kernel=kernel, dimension=D, normalize_rows=normalize, precision=precision, device=0, comm=comm)
+        try:
+            algo.prepare_data(source_points=y, target_points=y if x is None else x, same_points=x is None)
+            algo.fit()
+            algo.prepare_query(source_signal=b)
+            algo.query()
+            got = algo.get_result()
+            meta = algo.get_additional()
+            lo, hi = algo.shard
+        finally:
+            algo.done()
+        want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b, normalize_rows=normalize)
+        e = rel(got, want)
+        assert meta["rccl_ranks"] == world and meta["n_gpus"] == world, meta
+        assert hi - lo == sharding.shard_range(n, rank, world)[1] - sharding.shard_range(n, rank, world)[0]
+        assert np.isfinite(got).all() and e <= tol, (kernel, precision, n, e, tol, meta)
+        report.append({"kernel": kernel, "precision": str(precision), "n": n, "shard": [lo, hi], "rel_err": e,
+                       "device_kernel": meta["device_kernel"]})
+
+    # sharded solvers: replicated Krylov vectors, operator summed over the ranks in every iteration
+    for kernel, n, rtol in (("gaussian", 3000, 1e-6), ("inverse-distance", 2000, 1e-8)):
+        y, b = kmvp_oracle.uniform_cube(n, 3)
+        a = kmvp_oracle.product(kernel=kernel, source_points=y, source_signal=b)
+        algo = MI355XSolver(kernel=kernel, dimension=3, precision=np.float64, device=0, rtol=rtol, maxit=4000, comm=comm)
+        try:
+            algo.prepare_data(source_points=y)
+            algo.fit()
+            algo.prepare_query(target_signal=a)
+            algo.query()
+            sol = algo.get_result()
+            meta = algo.get_additional()
+        finally:
+            algo.done()
+        res = float(np.linalg.norm(kmvp_oracle.product(kernel=kernel, source_points=y, source_signal=sol) - a) / np.linalg.norm(a))
+        assert meta["cg_converged"] and res <= 2 * rtol, (kernel, res, meta)
+        report.append({"solver": kernel, "n": n, "iterations": meta["cg_iterations"], "true_residual": res})
+
+    # every rank must hold the same answers: compare a digest
+    import torch
+
+    digest = torch.tensor([sum(r.get("rel_err", r.get("true_residual", 0.0)) for r in report)], dtype=torch.float64)
+    lo_t, hi_t = digest.clone(), digest.clone()
+    dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+    assert float(lo_t[0]) == float(hi_t[0]), "ranks disagree on the results"
+    if rank == 0:
+        print(json.dumps({"world": world, "cases": report}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

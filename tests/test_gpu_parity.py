@@ -1337,6 +1337,47 @@ def test_config4_inverse_distance_one_of_eight_shards_at_full_size():
     print(f"config 4 shard: {kname} {ms:.1f} ms, {n * (hi - lo) / ms / 1e9:.2f}e12 pairs/s, {dev_gb:.2f} GB, rel err {err:.2e}")
 
 
+def test_config4_all_eight_shards_sum_to_the_whole_product_at_full_size():
+    """C4's whole arithmetic on the one GPU a test box has: the eight ranks' source slices (sharding.shard_range, the
+    plugin's own split) run one after the other -- same context, `partial_shard` = 1, j_offset / M_total of each rank --
+    and their float64 partial sums are added on the host, which is what the single RCCL all-reduce of SURVEY 8e does.
+    Checks: every row of the sum finite (each target's zero column, bruteforce.py:8-15, lies in exactly one slice and
+    must be zeroed there and nowhere else); 512 rows -- incl. the rows on both sides of every slice edge, whose zero
+    column is the first / last source of a slice -- against the float64 C oracle on ALL 1e7 sources."""
+    from kernel_matrix_benchmarks_amd import sharding
+
+    n, world = 10_000_000, 8
+    y, b = kmvp_oracle.uniform_cube(n, 3)  # seed 10000003
+    y32 = y.astype(np.float32)
+    b32 = b.astype(np.float32)
+    total = np.zeros((n, 1))
+    edges, ms_all, names = [], [], set()
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_option("same_points_global", 1)
+        ctx.set_option("partial_shard", 1)
+        for rank in range(world):
+            lo, hi = sharding.shard_range(n, rank, world)
+            edges += [lo, min(lo + 1, n - 1), hi - 2, hi - 1]
+            ctx.set_points(np.ascontiguousarray(y32[lo:hi]), y32, _lib.KMVP_F32, j_offset=lo, M_total=n)
+            ctx.set_signal(np.ascontiguousarray(b32[lo:hi]))
+            ctx.run("inverse-distance", False)
+            names.add(ctx.last_kernel_name)
+            ms_all.append(ctx.last_kernel_ms)
+            part = ctx.get_result(n, 1)
+            assert np.isfinite(part).all(), f"shard {rank}: non-finite partial sums"
+            total += part
+    finally:
+        ctx.close()
+    assert names == {"cfast_kernel"}, names
+    rows = np.unique(np.concatenate([np.random.RandomState(8).choice(n, size=512 - len(edges), replace=False), np.array(edges)]))
+    want = c_oracle.product(kernel="inverse-distance", source_points=y, source_signal=b, rows=rows)
+    err = np.max(np.abs(total[rows] - want)) / np.max(np.abs(want))
+    assert err <= 2 * TOL32, err
+    print(f"config 4, 8 shards on one GPU: {sum(ms_all):.0f} ms of pair loops ({n * float(n) / sum(ms_all) / 1e9:.2f}e12 pairs/s), "
+          f"{len(rows)} rows rel err {err:.2e}")
+
+
 def test_config5_gaussian_cg_solver_at_1e5_float64():
     """C5 exactly (Gaussian solver K b = a, N = M = 1e5, D = 3, float64, CG with the HIP matvec as operator,
     residual < 1e-6): uniform_cube(100000, 3) (seed 100003), a := K b from the float64 product,
@@ -1401,12 +1442,16 @@ def test_mixed_precision_refinement_reaches_the_float64_residual():
     x, info = out[1e-3]
     assert info["cg_converged"] and info["cg_relative_residual"] <= 1.5e-6, info
     assert info["inner_device_kernel"] == "cellmm_kernel" and info["refinement_steps"] >= 2, info
+    assert info["refinement_stop_reason"] == "tolerance" and np.isfinite(info["refinement_last_inner_residual"]), info
     Kx = c_oracle.product(kernel="gaussian", source_points=y, source_signal=x, rows=rows)
     assert np.linalg.norm(Kx - a[rows]) / np.linalg.norm(a[rows]) <= 5e-6
     x6, info6 = out[1e-6]
     assert np.isfinite(x6).all() and np.isfinite(info6["cg_relative_residual"])
     if not info6["cg_converged"]:
         assert info6["cg_relative_residual"] <= 1.0  # the last good iterate (at worst x = 0), not a diverged one
+        assert info6["refinement_stop_reason"] in ("stagnation", "maxit", "outer-limit", "non-finite"), info6
+    else:
+        assert info6["refinement_stop_reason"] == "tolerance", info6
     with pytest.raises(NotImplementedError):
         MI355XSolver(kernel="inverse-distance", dimension=3, precision=np.float64, refine="float32")
     with pytest.raises(NotImplementedError):
