@@ -69,10 +69,12 @@ def main():
                        "device_kernel": meta["device_kernel"]})
 
     # sharded solvers: replicated Krylov vectors, operator summed over the ranks in every iteration
-    for kernel, n, rtol in (("gaussian", 3000, 1e-6), ("inverse-distance", 2000, 1e-8)):
+    for kernel, n, rtol in (("gaussian", 3000, 1e-6), ("inverse-distance", 1500, 1e-8)):
         y, b = kmvp_oracle.uniform_cube(n, 3)
+        if kernel == "inverse-distance":  # the reference's own solver datasets: well-conditioned (datasets.py:393-399)
+            y = kmvp_oracle.uniform_sphere_points(n)
         a = kmvp_oracle.product(kernel=kernel, source_points=y, source_signal=b)
-        algo = MI355XSolver(kernel=kernel, dimension=3, precision=np.float64, device=0, rtol=rtol, maxit=4000, comm=comm)
+        algo = MI355XSolver(kernel=kernel, dimension=3, precision=np.float64, device=0, rtol=rtol, maxit=20000, comm=comm)
         try:
             algo.prepare_data(source_points=y)
             algo.fit()
