@@ -107,6 +107,17 @@ int kmvp_absexp(kmvp_ctx* ctx);
 int kmvp_absexp_norm(kmvp_ctx* ctx);
 int kmvp_invdist(kmvp_ctx* ctx);
 int kmvp_invdist_norm(kmvp_ctx* ctx);
+/* k(x, y) = exp(<x, y>): the attention kernel the reference's README defines (README.md:51-59; no reference plugin
+ * computes it: parity unpinned).  float32, D <= 64, a signal must be set (density estimation: pass ones).  S = X Y^T
+ * comes straight from the matrix cores (3-way split bf16 operands, fp32 accuracy), the kernel values are taken relative
+ * to a per-target running maximum exponent (flash-attention recurrence with integer exponents: kmvp_fastmm.hpp) and
+ * leave the pair loop as (mantissa sums, exponent) pairs, so that
+ *   kmvp_expdot_norm  softmax attention  a_i = sum_j e^<x_i,y_j> b_j / sum_j e^<x_i,y_j>   has NO range limit on <x, y>;
+ *   kmvp_expdot       plain product: overflows to inf exactly where exp(<x, y>) leaves the float64 range.
+ * Sharded: all-reduce(min) of the exponents, then the usual all-reduce(sum).  Other dtypes / D: KMVP_E_UNSUPPORTED
+ * (the plugin then uses the Gaussian identity, with its range check). */
+int kmvp_expdot(kmvp_ctx* ctx);
+int kmvp_expdot_norm(kmvp_ctx* ctx);
 
 /* BaseProduct.get_result (base.py:107-116): (N,E) float64 row-major. */
 int kmvp_get_result(kmvp_ctx* ctx, double* out, int64_t out_len);
@@ -146,10 +157,11 @@ int kmvp_comm_rank(const kmvp_ctx* ctx);
  * so the multi-rank path of this library -- shard-local kernels with j_offset / M_total, the canonical unpadded
  * [column][N] layout, exchange, normalisation, the sharded solvers -- cannot be exercised with world > 1 on a
  * one-GPU box through kmvp_comm_init.  With this entry the all-reduce is staged through host memory instead:
- * `fn(user, buf, count)` must sum `count` doubles in place over all ranks (e.g. torch.distributed.all_reduce
- * over gloo) and return 0.  Everything else -- what is exchanged, where in the stream, what happens before and
+ * `fn(user, buf, count, op)` must reduce `count` doubles in place over all ranks -- op = KMVP_OP_SUM, or KMVP_OP_MIN
+ * (the exponents of the exp(<x,y>) path) -- e.g. by torch.distributed.all_reduce over gloo, and return 0.  Everything else -- what is exchanged, where in the stream, what happens before and
  * after -- is the code path kmvp_comm_init uses.  Never selected implicitly. */
-typedef int (*kmvp_host_allreduce_fn)(void* user, double* buf, int64_t count);
+enum kmvp_reduce_op { KMVP_OP_SUM = 0, KMVP_OP_MIN = 1 };
+typedef int (*kmvp_host_allreduce_fn)(void* user, double* buf, int64_t count, int op);
 int kmvp_comm_init_host(kmvp_ctx* ctx, kmvp_host_allreduce_fn fn, void* user, int rank, int world);
 
 /* BaseAlgorithm.set_query_arguments (base.py:40-42): tuning knobs, all optional.

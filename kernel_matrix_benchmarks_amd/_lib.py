@@ -35,6 +35,8 @@ SYMBOLS = [
     ("kmvp_absexp_norm", _c.c_int, [_c.c_void_p]),
     ("kmvp_invdist", _c.c_int, [_c.c_void_p]),
     ("kmvp_invdist_norm", _c.c_int, [_c.c_void_p]),
+    ("kmvp_expdot", _c.c_int, [_c.c_void_p]),
+    ("kmvp_expdot_norm", _c.c_int, [_c.c_void_p]),
     ("kmvp_get_result", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64]),
     ("kmvp_gaussian_cg_solve", _c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_double, _c.c_int,
                                           _c.c_void_p, _c.POINTER(_c.c_int), _c.POINTER(_c.c_double)]),
@@ -56,7 +58,8 @@ SYMBOLS = [
     ("kmvp_last_dispatch_note", _c.c_char_p, [_c.c_void_p]),
 ]
 
-HOST_ALLREDUCE_FN = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.POINTER(_c.c_double), _c.c_int64)
+HOST_ALLREDUCE_FN = _c.CFUNCTYPE(_c.c_int, _c.c_void_p, _c.POINTER(_c.c_double), _c.c_int64, _c.c_int)
+OP_SUM, OP_MIN = 0, 1
 
 _lib = None
 
@@ -168,6 +171,8 @@ class Context:
             ("absolute-exponential", True): self._lib.kmvp_absexp_norm,
             ("inverse-distance", False): self._lib.kmvp_invdist,
             ("inverse-distance", True): self._lib.kmvp_invdist_norm,
+            ("exp-dot", False): self._lib.kmvp_expdot,
+            ("exp-dot", True): self._lib.kmvp_expdot_norm,
         }[(kernel, bool(normalize_rows))]
         self._check(entry(self._ctx))
 
@@ -203,12 +208,13 @@ class Context:
         self.comm_world = int(world)  # attachment is recorded on the context itself (sharding.Communicator.attach)
 
     def comm_init_host(self, allreduce, rank, world):
-        """REHEARSAL transport (include/kmvp.h kmvp_comm_init_host): ``allreduce(array)`` must sum a float64 numpy
-        array in place over all ranks.  The library stages the exchange buffer through host memory and calls it."""
+        """REHEARSAL transport (include/kmvp.h kmvp_comm_init_host): ``allreduce(array, op)`` must reduce a float64
+        numpy array in place over all ranks (op: OP_SUM or OP_MIN).  The library stages the exchange buffer through
+        host memory and calls it."""
 
-        def trampoline(_user, buf, count):
+        def trampoline(_user, buf, count, op):
             try:
-                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)), int(op))
                 return 0
             except Exception as e:  # never let a Python exception cross the C frame
                 self._host_error = e

@@ -29,14 +29,23 @@ from kernel_matrix_benchmarks_amd import sharding
 SUPPORTED_KERNELS = ("gaussian", "absolute-exponential", "inverse-distance", "exp-dot")
 # "exp-dot": k(x, y) = exp(<x, y>), the transformer attention kernel the reference's README defines
 # (README.md:51-59) but its plugins do not implement (bruteforce.py:18-22 has the other three): parity
-# unpinned, checked against a direct numpy evaluation only.  Computed through the identity
-#     exp(<x, y>) = exp(|x|^2 / 2) * exp(-|x/sqrt2 - y/sqrt2|^2) * exp(|y|^2 / 2)
-# i.e. a GAUSSIAN product on the points / sqrt(2) with the signal weighted by w_j = exp(|y_j|^2/2 - c)
-# (c = max_j |y_j|^2/2, so w <= 1) -- every Gaussian kernel of the library serves it, the cell form included.
-# Row-normalised ("softmax attention"): (K (w b)) / (K w), the factor of the target cancels; plain products
-# multiply it back in float64.  Valid while |y_j|^2/2 spans less than the exponent range of the working
-# precision (~80 for float32); an online-max formulation would lift that and is not built.
+# unpinned, checked against a direct numpy evaluation only (the tests' exp_dot_product).  Two routes:
+#  * NATIVE (float32 / float16 inputs, D <= 64; include/kmvp.h kmvp_expdot[_norm]): S = X Y^T straight from the
+#    matrix cores, kernel values relative to a per-target running maximum exponent (the flash-attention
+#    recurrence), partial sums merged as (mantissa, exponent) pairs -- softmax attention has NO range limit on
+#    <x, y>; plain products overflow where exp(<x, y>) leaves float64, as numpy's would.
+#  * IDENTITY (float64, bfloat16, D > 64, and the solver):
+#        exp(<x, y>) = exp(|x|^2 / 2) * exp(-|x/sqrt2 - y/sqrt2|^2) * exp(|y|^2 / 2)
+#    i.e. a GAUSSIAN product on the points / sqrt(2) with the signal weighted by w_j = exp(|y_j|^2/2 - c)
+#    (c = max_j |y_j|^2/2, so w <= 1) -- every Gaussian kernel of the library serves it.  Row-normalised: (K (w b)) /
+#    (K w), the factor of the target cancels; plain products multiply it back in float64.  Valid while
+#    |y_j|^2/2 spans less than the exponent range of the working precision: checked in prepare_data
+#    (EXPDOT_IDENTITY_SPREAD), NotImplementedError beyond it -- never a silent zero weight.
 SQRT_HALF = 0.7071067811865476
+EXPDOT_NATIVE_MAX_D = 64
+# largest spread max_j |y_j|^2/2 - min_j |y_j|^2/2 the identity route accepts: the smallest weight is exp(-spread);
+# float32 / bfloat16 (8-bit exponent): e^-80 = 2^-115 is still a normal number; float64: e^-700
+EXPDOT_IDENTITY_SPREAD = {"float32": 80.0, "float64": 700.0}
 
 
 def _sq_norms_on_device(p_scaled, bf16):
@@ -71,6 +80,7 @@ class MI355XProduct(BaseProduct):
             # same failure mode as bruteforce.py:82-85
             raise NotImplementedError(f"MI355XProduct doesn't support kernel {kernel}.")
         self._dot = kernel == "exp-dot"
+        self._dot_native = False  # decided in prepare_data (needs D)
         self._device_kernel_fn = "gaussian" if self._dot else kernel
         self._dtype_code, self._host_dtype = _lib.dtype_code(precision)  # NotImplementedError if unknown
         # precision="float16" (algos.yaml:157): inputs rounded to float16 as the reference casts them
@@ -106,7 +116,11 @@ class MI355XProduct(BaseProduct):
         # h5py hands numpy.bool_ attributes over (runner.py:41-43)
         self.same_points = bool(same_points)
         self.density_estimation = bool(density_estimation)
+        self._dot_note = ""
         if self._dot:
+            self._dot_native = (self._dtype_code == _lib.KMVP_F32 and np.asarray(source_points).shape[1] <= EXPDOT_NATIVE_MAX_D)
+            self._device_kernel_fn = "exp-dot" if self._dot_native else "gaussian"
+        if self._dot and not self._dot_native:
             # the caller's points in the working precision first (what the kernel is defined on), then the identity
             ys = np.asarray(self._cast(source_points), dtype=np.float64)
             xs = ys if self.same_points else np.asarray(self._cast(target_points), dtype=np.float64)
@@ -116,6 +130,16 @@ class MI355XProduct(BaseProduct):
             hy = _sq_norms_on_device(self._cast(source_points), bf16)   # |y/sqrt2|^2 = |y|^2 / 2
             hx = hy if self.same_points else _sq_norms_on_device(self._cast(target_points), bf16)
             shift = float(np.max(hy)) if len(hy) else 0.0
+            spread = float(shift - np.min(hy)) if len(hy) else 0.0
+            budget = EXPDOT_IDENTITY_SPREAD["float64" if self._dtype_code == _lib.KMVP_F64 else "float32"]
+            self._dot_note = (f"exp-dot through the Gaussian identity ({_precision_name(self.precision)}, D = {ys.shape[1]}): "
+                              f"|y|^2/2 spans {spread:.3g} of the {budget:g} this precision's exponent range allows")
+            if not spread <= budget:
+                raise NotImplementedError(
+                    f"exp-dot through the Gaussian identity: |y_j|^2/2 spans {spread:.4g} > {budget:g}; sources of small norm "
+                    f"would silently get weight 0 in {_precision_name(self.precision)}.  Use precision='float32' with D <= "
+                    f"{EXPDOT_NATIVE_MAX_D} (native online-max kernel, no range limit) or float64 (spread <= "
+                    f"{EXPDOT_IDENTITY_SPREAD['float64']:g}).")
             self._w = np.exp(hy - shift).reshape(-1, 1)   # source weights, <= 1
             self._hx = hx + shift                         # log of the target factor exp(|x|^2/2 + c)
         y = self._cast(source_points)
@@ -159,7 +183,9 @@ class MI355XProduct(BaseProduct):
             self._ctx.set_points(y, x, self._dtype_code)
 
     def prepare_query(self, *, source_signal):
-        if self._dot:
+        if self._dot_native and self.density_estimation:
+            source_signal = np.ones((self.M, 1))  # the library's exp(<x,y>) entry takes an explicit signal
+        if self._dot and not self._dot_native:
             # weighted signal [w b | w]: numerator columns and (normalised rows) the denominator column
             b = np.ones((self.M, 1)) if self.density_estimation else np.asarray(self._cast(source_signal), dtype=np.float64)
             if b.ndim == 1:
@@ -174,7 +200,7 @@ class MI355XProduct(BaseProduct):
                 wb = wb[self._order]
             self._ctx.set_signal(np.ascontiguousarray(wb[lo:hi]))
             return
-        if self.density_estimation:
+        if self.density_estimation and not self._dot_native:
             self._ctx.set_signal(None)
             self.E = 1
             return
@@ -191,7 +217,7 @@ class MI355XProduct(BaseProduct):
         self._ctx.set_signal(np.ascontiguousarray(b[lo:hi]))
 
     def get_result(self):
-        if self._dot:
+        if self._dot and not self._dot_native:
             if self.normalize_rows:
                 res = self._ctx.get_result(self.N, self.E + 1)
                 return np.ascontiguousarray(res[:, : self.E] / res[:, self.E:])  # exp(|x_i|^2/2) cancels
@@ -203,11 +229,12 @@ class MI355XProduct(BaseProduct):
     def fit(self):
         """The kernel matrix is never formed; what the points alone determine (grid, cell order and tile
         lists of the Gaussian cell kernels) is built here, as the reference builds its structure in fit()."""
-        self._ctx.fit(self._device_kernel_fn)
+        if not self._dot_native:  # (the native exp(<x,y>) path has nothing the points alone determine)
+            self._ctx.fit(self._device_kernel_fn)
 
     def query(self):
         # synchronous: the device (and the all-reduce) is done when this returns
-        self._ctx.run(self._device_kernel_fn, self.normalize_rows and not self._dot)
+        self._ctx.run(self._device_kernel_fn, self.normalize_rows and (self._dot_native or not self._dot))
         self.res = None  # the result stays on the device until get_result()
 
     # -- bookkeeping ---------------------------------------------------------------
@@ -248,7 +275,7 @@ class MI355XProduct(BaseProduct):
             "rccl_ranks": self._ctx.rccl_ranks,
             "allreduce_ms": self._ctx.last_allreduce_ms,
             # "" or why a faster form was not taken (too few points per grid cell, the radius rule, ...)
-            "dispatch_note": self._ctx.last_dispatch_note,
+            "dispatch_note": self._ctx.last_dispatch_note or getattr(self, "_dot_note", ""),
         }
 
     def done(self):
@@ -369,6 +396,21 @@ class MI355XSolver(BaseSolver):
             self.res, self.iterations, self.residual, self.converged = self._ctx.cg_solve(
                 self._device_kernel_fn, self._a, self.rtol, self.maxit)
         if self._dot:
+            # The iteration ran on the SCALED system G z = D^-1 a (z = D b, D = diag(exp(|x|^2/2))); where D varies a lot
+            # its residual says little about K b = a.  The verdict is therefore taken on the unscaled system, from one
+            # more product:  a - K b = D (D^-1 a - G z).
+            z = np.ascontiguousarray(self.res, dtype=self._host_dtype)
+            self._ctx.set_signal(z)
+            self._ctx.run(self._device_kernel_fn, False)
+            r_scaled = np.asarray(self._a, dtype=np.float64) - self._ctx.get_result(self.M, z.shape[1])
+            with np.errstate(over="ignore", invalid="ignore"):
+                d = np.exp(self._hx).reshape(-1, 1)
+                num = np.linalg.norm(d * r_scaled, axis=0)
+                den = np.linalg.norm(d * np.asarray(self._a, dtype=np.float64), axis=0)
+                den[den == 0] = 1.0
+                self.scaled_residual = self.residual
+                self.residual = float(np.max(num / den))
+            self.converged = bool(np.isfinite(self.residual) and self.residual <= 1.5 * self.rtol)
             self.res = self.res * np.exp(-self._hx).reshape(-1, 1)  # b = D^-1 (D b)
 
     def _query_refined(self):
@@ -431,6 +473,8 @@ class MI355XSolver(BaseSolver):
         if self._ctx is not None:
             extra["device_kernel"] = self._ctx.last_kernel_name  # the operator's pair-loop kernel
             extra["rccl_ranks"] = self._ctx.rccl_ranks
+        if self._dot and hasattr(self, "scaled_residual"):
+            extra["cg_scaled_system_residual"] = self.scaled_residual  # of G (D b) = D^-1 a, what the iteration saw
         if self.refine and self._ctx32 is not None:
             extra["refinement_steps"] = self.outer_iterations
             extra["inner_device_kernel"] = self._ctx32.last_kernel_name

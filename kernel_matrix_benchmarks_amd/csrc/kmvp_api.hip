@@ -89,7 +89,7 @@ void kmvp_destroy(kmvp_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   for (DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled, &c->y_scaled,
-                    &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg,
+                    &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg, &c->kexp, &c->kshift, &c->xchgk,
                     &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre, &c->cell_scale})
     release(*b);
   for (int i = 0; i < 5; ++i)
@@ -168,6 +168,8 @@ int kmvp_absexp(kmvp_ctx* c) { return run_product(c, K_ABSEXP, false); }
 int kmvp_absexp_norm(kmvp_ctx* c) { return run_product(c, K_ABSEXP, true); }
 int kmvp_invdist(kmvp_ctx* c) { return run_product(c, K_INVDIST, false); }
 int kmvp_invdist_norm(kmvp_ctx* c) { return run_product(c, K_INVDIST, true); }
+int kmvp_expdot(kmvp_ctx* c) { return run_product(c, K_EXPDOT, false); }
+int kmvp_expdot_norm(kmvp_ctx* c) { return run_product(c, K_EXPDOT, true); }
 
 int kmvp_get_result(kmvp_ctx* c, double* out, int64_t out_len) {
   if (!c) return KMVP_E_INVALID;
@@ -301,7 +303,7 @@ int64_t kmvp_device_bytes(const kmvp_ctx* c) {
   if (!c) return 0;
   size_t t = 0;
   for (const DevBuf* b : {&c->y_raw, &c->x_raw, &c->b_raw, &c->xs, &c->rec, &c->x_scaled,
-                          &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg,
+                          &c->y_scaled, &c->part, &c->partd, &c->aux, &c->sortbuf, &c->perm, &c->sums, &c->out, &c->scratch, &c->xchg, &c->kexp, &c->kshift, &c->xchgk,
                           &c->cell_tperm, &c->cell_sperm, &c->cell_tgrp, &c->cell_sgrp, &c->cell_slot, &c->cell_tmeta, &c->cell_sums, &c->cell_skey, &c->cell_scentre, &c->cell_scale})
     t += b->cap;
   return (int64_t)t;

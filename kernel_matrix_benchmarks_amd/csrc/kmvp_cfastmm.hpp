@@ -39,14 +39,17 @@ struct CfastmmArgs {
   float scale;               // the kernel's constant, applied AFTER a difference is formed
 };
 
-// T = 2^FMM_SHIFT k(s)
+// T = 2^sh k(s), sh = FMM_SHIFT [+ the target's online shift]
 template <int KERNEL>
-__device__ __forceinline__ float cfm_tval(float s) {
-  if constexpr (KERNEL == K_GAUSSIAN) return kexp2((float)FMM_SHIFT - s);
-  else return kexp2((float)FMM_SHIFT - __builtin_amdgcn_sqrtf(__builtin_fabsf(s)));
+__device__ __forceinline__ float cfm_tval(float s, float sh) {
+  if constexpr (KERNEL == K_GAUSSIAN) return kexp2(sh - s);
+  else return kexp2(sh - __builtin_amdgcn_sqrtf(__builtin_fabsf(s)));
 }
 
-template <int KERNEL, int MODE, int TT>
+// ONLINE = 1: per-target running shift kop = floor(smallest exponent seen so far), T = 2^(15 + kop) k -- see "The shift" in
+// kmvp_fastmm.hpp.  Here the shift is a per-lane constant of the VALU subtraction that was there anyway; the pair loop
+// pays the running minimum of the tile (8 v_min3 + one v_permlane32_swap) and a rare wave-uniform rescale branch.
+template <int KERNEL, int MODE, int TT, int ONLINE = 0>
 __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArgs a) {
   static_assert(KERNEL == K_GAUSSIAN || KERNEL == K_ABSEXP, "bounded kernels only");
   constexpr int SB = cfm_stage_bytes(MODE);
@@ -73,8 +76,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
 
   f32x16 acc[TT];
   double accd[TT][NOUT];
+  float kop[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    kop[tt] = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
 #pragma unroll
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
         // rare branch (kmvp_cfast.hpp): pairs closer than sqrt(tau) get the exact difference form
         const bool gate = (near_mask >> tt) & 1u;
         float dmin = INFINITY;
-        if (gate) {
+        if (gate || ONLINE) {
           dmin = fminf(fminf(d[0], d[1]), d[2]);
 #pragma unroll
           for (int q = 3; q < 15; q += 2) dmin = fminf(fminf(dmin, d[q]), d[q + 1]);
@@ -185,12 +190,32 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
             }
           }
         }
+        if constexpr (ONLINE) {
+          // smallest exponent of the tile for this target (both lane halves): s for the Gaussian, r for exp(-r); the
+          // exactly recomputed pairs are >= 0 and at most tau away from what dmin saw
+          float m = fmm_min_halves(dmin);
+          if constexpr (KERNEL == K_ABSEXP) m = __builtin_amdgcn_sqrtf(fmaxf(m, 0.f));
+          else m = fmaxf(m, 0.f);
+          const bool first = s == s_begin && rt == 0;
+          const bool need = (first || m < kop[tt]) && m < 3.0e38f;
+          if (__any(need)) {  // rare
+            fold();
+            if (need) {
+              const float kn = floorf(m);
+              const int di = (int)(kop[tt] - kn);  // >= 0 except at the first tile (nothing accumulated yet)
+#pragma unroll
+              for (int q = 0; q < NOUT; ++q) accd[tt][q] = ldexp(accd[tt][q], -di);
+              kop[tt] = kn;
+            }
+          }
+        }
+        const float sh = (float)FMM_SHIFT + kop[tt];
         h16x8 th[2], tl[2];
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const fmm_f32x2 t = {cfm_tval<KERNEL>(d[8 * g2 + 2 * i]), cfm_tval<KERNEL>(d[8 * g2 + 2 * i + 1])};
+            const fmm_f32x2 t = {cfm_tval<KERNEL>(d[8 * g2 + 2 * i], sh), cfm_tval<KERNEL>(d[8 * g2 + 2 * i + 1], sh)};
             const h16x2 hh = __builtin_convertvector(t, h16x2);
             const fmm_f32x2 rest = {fmm_minus_lo_half(t[0], hh), fmm_minus_hi_half(t[1], hh)};
             const h16x2 ll = __builtin_convertvector(rest, h16x2);
@@ -221,8 +246,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
 #pragma unroll
     for (int q = 0; q < NOUT; ++q) {
       const int e = 8 * (q >> 2) + 4 * h + (q & 3);
-      if (e < a.NE)
-        a.part[((int64_t)seg * a.NE + e) * a.n_pad + (tile0 + tt) * 32 + r] = accd[tt][q] * a.unscale[e];
+      if (e < a.NE) {
+        double v = accd[tt][q] * a.unscale[e];
+        if constexpr (ONLINE) v = ldexp(v, -(int)kop[tt]);  // the true scale
+        a.part[((int64_t)seg * a.NE + e) * a.n_pad + (tile0 + tt) * 32 + r] = v;
+      }
     }
 }
 

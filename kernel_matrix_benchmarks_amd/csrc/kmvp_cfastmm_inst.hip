@@ -5,23 +5,27 @@
 
 namespace kmvp {
 
-template <int KERNEL, int MODE>
+template <int KERNEL, int MODE, int ONLINE>
 static hipError_t launch_tt(int TT, const CfastmmArgs& args, dim3 grid, hipStream_t stream) {
   switch (TT) {
-    case 1: hipLaunchKernelGGL((cfastmm_kernel<KERNEL, MODE, 1>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
-    case 2: hipLaunchKernelGGL((cfastmm_kernel<KERNEL, MODE, 2>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
+    case 1: hipLaunchKernelGGL((cfastmm_kernel<KERNEL, MODE, 1, ONLINE>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
+    case 2: hipLaunchKernelGGL((cfastmm_kernel<KERNEL, MODE, 2, ONLINE>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_cfastmm(int kernel, int mode, int TT, const CfastmmArgs& args, dim3 grid, hipStream_t stream,
+template <int KERNEL>
+static hipError_t launch_mode(int mode, int TT, int online, const CfastmmArgs& args, dim3 grid, hipStream_t stream) {
+  if (online) return mode ? launch_tt<KERNEL, 1, 1>(TT, args, grid, stream) : launch_tt<KERNEL, 0, 1>(TT, args, grid, stream);
+  return mode ? launch_tt<KERNEL, 1, 0>(TT, args, grid, stream) : launch_tt<KERNEL, 0, 0>(TT, args, grid, stream);
+}
+
+hipError_t launch_cfastmm(int kernel, int mode, int TT, int online, const CfastmmArgs& args, dim3 grid, hipStream_t stream,
                           const char** kernel_name) {
-  if (kernel_name) *kernel_name = "cfastmm_kernel";
-  if (kernel == K_GAUSSIAN)
-    return mode ? launch_tt<K_GAUSSIAN, 1>(TT, args, grid, stream) : launch_tt<K_GAUSSIAN, 0>(TT, args, grid, stream);
-  if (kernel == K_ABSEXP)
-    return mode ? launch_tt<K_ABSEXP, 1>(TT, args, grid, stream) : launch_tt<K_ABSEXP, 0>(TT, args, grid, stream);
+  if (kernel_name) *kernel_name = online ? "cfastmm_online_kernel" : "cfastmm_kernel";
+  if (kernel == K_GAUSSIAN) return launch_mode<K_GAUSSIAN>(mode, TT, online, args, grid, stream);
+  if (kernel == K_ABSEXP) return launch_mode<K_ABSEXP>(mode, TT, online, args, grid, stream);
   return hipErrorInvalidValue;
 }
 

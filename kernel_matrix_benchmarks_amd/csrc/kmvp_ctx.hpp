@@ -120,6 +120,7 @@ struct kmvp_ctx {
   DevBuf cell_tperm, cell_sperm, cell_tgrp, cell_sgrp, cell_slot, cell_tmeta, cell_sums, cell_skey, cell_scentre, cell_scale;
   DevBuf part, sums, out;       // fp64 partials, reduced sums, final (N,E)
   DevBuf xchg;                  // sharded runs: sums in the canonical unpadded layout [column][N] for the all-reduce
+  DevBuf kexp, kshift, xchgk;   // exp(<x,y>): exponents per (segment, target) / per target / per target after the all-reduce(min)
   DevBuf scratch;               // CG vectors / dot products
   uint64_t points_ver = 0, signal_ver = 0;
   // what xs / rec / scaled copies currently hold

@@ -28,8 +28,26 @@
 //
 // Per 32 x 32 pairs and lane: 16 v_exp_f32 + 16 v_cvt_pk_f16_f32 + 16 v_fma_mix_f32 against 16 (1 + E) FMAs +
 // 16 v_exp_f32 of a VALU sum, and KS + 4 (6) MFMAs of 8 passes beside them (331 issue cycles, measured
-// 335).  Error: T and b are carried to 2^-22, s as in fast_kernel (eps32 (|x'|^2 + |y'|^2), clouds inside the radius
-// rule) -- measured in tests/test_gpu_parity.py.
+// 335).  Error: b is carried to 2^-22; a kernel value T = 2^15 k is carried to 2^-22 RELATIVE while T >= 2^-3 and to
+// 2^-25 ABSOLUTE below that (T_l goes subnormal), i.e. to 2^-40 of the LARGEST value the shift was chosen for; s as in
+// fast_kernel (eps32 (|x'|^2 + |y'|^2), clouds inside the radius rule) -- measured in tests/test_gpu_parity.py.
+//
+// The shift (ONLINE).  With the fixed shift 2^15 the largest value is k = 1: right when every target has a source at
+// distance ~0 (targets == sources), wrong for a target far from every source -- its whole row sits near or below the
+// f16 floor (rows 3.8 / 4.5 away came out 5e-2 off / NaN).  ONLINE = 1 carries a per-TARGET integer shift
+// kop, the flash-attention recurrence with the running maximum rounded to an integer power of two:
+//     T = 2^(15 + kop) k ,   kop = floor(log2 of 1 / (largest k seen so far for this target))
+//  * Gaussian / exp(<x,y>): the shift rides in the MFMA operands -- column 16 KS - 1 of the target row holds -kop
+//    (a bf16-exact integer: kop is rounded DOWN to 8 significant bits), the source rows hold 1 there -- so the
+//    pair loop pays only the running minimum of S (8 v_min3 + one v_permlane32_swap per tile);
+//  * exp(-r): T = exp2(15 + kop - sqrt(S)), the per-lane constant replaces the literal 15 (free);
+//  * when a tile would exceed 2^15 (or at a wave's first tile) the fp32 accumulator is folded into the fp64 sums,
+//    these are rescaled by 2^(kop_new - kop_old) <= 1 (exact), the tile's S is shifted and the operand patched:
+//    a rare wave-uniform branch.  kop only decreases, so nothing ever overflows; what a smaller, earlier value
+//    loses is below 2^-40 of the row's largest term.
+// The partial sums leave as fp64 at the true scale (x 2^-kop), or -- exp(<x,y>), FastmmArgs::kexp -- at the scale
+// 2^-kop together with kop per (segment, target), for a reduction that never forms exp(max logit)
+// (reduce_shifted_kernel in kmvp_product.hip: "no range limit" for row-normalised attention).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -78,6 +96,8 @@ struct FastmmArgs {
   int D;
   float scale;               // the kernel's constant, applied AFTER a difference is formed
   float tau;                 // pairs with s <= tau are recomputed in the difference form
+  float* kexp;               // ONLINE only; nullptr: the partial sums are written at the true scale; else they are
+                             // written at 2^-kop and kexp[segment][n_pad] receives kop (exp(<x,y>))
 };
 
 // t - (float)pair[0] and t - (float)pair[1] in ONE instruction each: v_fma_mix_f32 reads an f16 half of a register as
@@ -94,11 +114,25 @@ __device__ __forceinline__ float fmm_minus_hi_half(float t, h16x2 pair) {
   return r;
 }
 
-// T = 2^FMM_SHIFT k(s).  Gaussian: the shift rides in the operands (S = s - 15); exp(-r): S = s, one v_sqrt_f32 more.
+// T = 2^sh k(s).  Gaussian: the shift rides in the operands (S = s - sh); exp(-r): S = s, one v_sqrt_f32 more.
 template <int KERNEL>
-__device__ __forceinline__ float fmm_tval(float S) {
+__device__ __forceinline__ float fmm_tval(float S, float sh) {
   if constexpr (KERNEL == K_GAUSSIAN) return kexp2(-S);
-  else return kexp2((float)FMM_SHIFT - __builtin_amdgcn_sqrtf(__builtin_fabsf(S)));
+  else return kexp2(sh - __builtin_amdgcn_sqrtf(__builtin_fabsf(S)));
+}
+
+// largest bf16-representable value <= v (v an integer-valued float): the shift that goes into a bf16 operand
+__device__ __forceinline__ float fmm_bf16_floor(float v) {
+  const unsigned u = (unsigned)__float_as_int(v);
+  unsigned t = u & 0xffff0000u;
+  if ((int)u < 0 && (u & 0xffffu)) t += 0x10000u;  // negative: towards -inf
+  return __int_as_float((int)t);
+}
+
+// min over the two lane halves (lanes l and l ^ 32 hold the two halves of one target's sources): one VALU swap
+__device__ __forceinline__ float fmm_min_halves(float m) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fminf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
 }
 
 // the difference form of one pair from the caller's coordinates (rare branch of the exp(-r) variant; kept out of line:
@@ -113,7 +147,7 @@ __device__ __attribute__((noinline)) float fmm_exact_sqdist(const float* __restr
   return sx;
 }
 
-template <int KS, int MODE, int TT, int KERNEL = K_GAUSSIAN>
+template <int KS, int MODE, int TT, int KERNEL = K_GAUSSIAN, int ONLINE = 0>
 __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs a) {
   static_assert(KERNEL == K_GAUSSIAN || KERNEL == K_ABSEXP, "bounded kernels only");
   constexpr int RB = fmm_row_bytes(KS);
@@ -143,8 +177,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
 
   f32x16 acc[TT];
   double accd[TT][NOUT];
+  float kop[TT];  // ONLINE: the target's current shift (integer valued); acc and accd are sums of 2^(15 + kop) k b
+  bool kset[TT];  // ... and whether any live source has set it yet
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    kop[tt] = 0.f;
+    kset[tt] = false;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
 #pragma unroll
@@ -225,14 +263,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         f32x16 d = dc[tt];
+        float dmin = 0.f;
+        if constexpr (KERNEL == K_ABSEXP || ONLINE) {
+          dmin = fminf(fminf(d[0], d[1]), d[2]);
+#pragma unroll
+          for (int qq = 3; qq < 15; qq += 2) dmin = fminf(fminf(dmin, d[qq]), d[qq + 1]);
+          dmin = fminf(dmin, d[15]);
+        }
         if constexpr (KERNEL == K_ABSEXP) {
           // exp(-r) hinges on the RELATIVE accuracy of small s, the expansion around one centre has an absolute error
           // ~1e-7 R^2: pairs with s <= tau = kappa R^4 (the host's bound; in practice coincident and nearly coincident
           // points) are recomputed in the difference form from the caller's coordinates -- a wave-uniform rare branch
-          float dmin = fminf(fminf(d[0], d[1]), d[2]);
-#pragma unroll
-          for (int qq = 3; qq < 15; qq += 2) dmin = fminf(fminf(dmin, d[qq]), d[qq + 1]);
-          dmin = fminf(dmin, d[15]);
           if (__any(!(dmin > a.tau))) {
             const int64_t it = (tile0 + tt) * FAST_TILE + r;
             const int64_t j0 = (s * ST + q) * FAST_TILE;
@@ -243,12 +284,45 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
             }
           }
         }
+        if constexpr (ONLINE) {
+          // the target's closest source of this tile, over both lane halves.  Gaussian / exp(<x,y>): m = min S, the
+          // tile's largest T is 2^-m; exp(-r): m = min r (the exactly recomputed pairs are >= 0 and at most tau away
+          // from what dmin saw), the largest T is 2^(15 + kop - m).
+          float m = fmm_min_halves(dmin);
+          if constexpr (KERNEL == K_ABSEXP) m = __builtin_amdgcn_sqrtf(fmaxf(m, 0.f));
+          const bool first = s == s_begin && q == 0;
+          const bool need = (first || (KERNEL == K_ABSEXP ? m < kop[tt] : m < -(float)FMM_SHIFT)) && m < 3.0e38f;
+          if (__any(need)) {  // rare: see the header
+            fold();
+            if (need) {
+              float kn;
+              if constexpr (KERNEL == K_ABSEXP) kn = floorf(m);
+              else kn = fmm_bf16_floor(kop[tt] + floorf(m + (float)FMM_SHIFT));
+              const float delta = kop[tt] - kn;  // >= 0 except at the first tile
+              if constexpr (KERNEL != K_ABSEXP) {
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) d[qq] += delta;
+                if (q + 1 < ST) {  // the next tile's distances were issued with the old operand
+#pragma unroll
+                  for (int qq = 0; qq < 16; ++qq) dn[tt][qq] += delta;
+                }
+                if (h == 1) xb[tt][KS - 1][7] = (__bf16)(-kn);
+              }
+              const int di = (int)delta;
+#pragma unroll
+              for (int qq = 0; qq < NOUT; ++qq) accd[tt][qq] = ldexp(accd[tt][qq], -di);
+              kop[tt] = kn;
+              kset[tt] = true;
+            }
+          }
+        }
+        const float sh = (float)FMM_SHIFT + kop[tt];
         h16x8 th[2], tl[2];
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const fmm_f32x2 t = {fmm_tval<KERNEL>(d[8 * g2 + 2 * i]), fmm_tval<KERNEL>(d[8 * g2 + 2 * i + 1])};
+            const fmm_f32x2 t = {fmm_tval<KERNEL>(d[8 * g2 + 2 * i], sh), fmm_tval<KERNEL>(d[8 * g2 + 2 * i + 1], sh)};
             const h16x2 hh = __builtin_convertvector(t, h16x2);
             const fmm_f32x2 rest = {fmm_minus_lo_half(t[0], hh), fmm_minus_hi_half(t[1], hh)};
             const h16x2 ll = __builtin_convertvector(rest, h16x2);
@@ -280,9 +354,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
 #pragma unroll
     for (int q = 0; q < NOUT; ++q) {
       const int e = 8 * (q >> 2) + 4 * h + (q & 3);
-      if (e < a.NE)
-        a.part[((int64_t)seg * a.NE + e) * a.n_pad + (tile0 + tt) * FAST_TILE + r] = accd[tt][q] * a.unscale[e];
+      if (e < a.NE) {
+        double v = accd[tt][q] * a.unscale[e];
+        if constexpr (ONLINE) {
+          if (!a.kexp) v = ldexp(v, -(int)kop[tt]);  // the true scale
+        }
+        a.part[((int64_t)seg * a.NE + e) * a.n_pad + (tile0 + tt) * FAST_TILE + r] = v;
+      }
     }
+  if constexpr (ONLINE) {
+    if (a.kexp && h == 0) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)  // +inf: this segment saw no live source for the target
+        a.kexp[(int64_t)seg * a.n_pad + (tile0 + tt) * FAST_TILE + r] = kset[tt] ? kop[tt] : INFINITY;
+    }
+  }
 }
 
 }  // namespace kmvp

@@ -11,13 +11,13 @@
 
 namespace kmvp {
 
-template <int KS, int MODE, int KERNEL>
+template <int KS, int MODE, int KERNEL, int ONLINE>
 static hipError_t launch_tt(int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
   switch (TT) {
-    case 1: hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 1, KERNEL>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
+    case 1: hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 1, KERNEL, ONLINE>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;
     case 2:
       if constexpr (KS <= FMM_MAX_KS_TWO_TILES) {
-        hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 2, KERNEL>), grid, dim3(BLOCK_THREADS), 0, stream, args);
+        hipLaunchKernelGGL((fastmm_kernel<KS, MODE, 2, KERNEL, ONLINE>), grid, dim3(BLOCK_THREADS), 0, stream, args);
         break;
       }
       return hipErrorInvalidValue;
@@ -26,15 +26,21 @@ static hipError_t launch_tt(int TT, const FastmmArgs& args, dim3 grid, hipStream
   return hipGetLastError();
 }
 
+static int g_online = 0;  // set by KMVP_FN for the duration of one dispatch (the context is single-threaded)
+
 template <int KS>
 static hipError_t launch_mode(int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
-  return mode ? launch_tt<KS, 1, KMVP_FMM_KERNEL>(TT, args, grid, stream)
-              : launch_tt<KS, 0, KMVP_FMM_KERNEL>(TT, args, grid, stream);
+  if (g_online)
+    return mode ? launch_tt<KS, 1, KMVP_FMM_KERNEL, 1>(TT, args, grid, stream)
+                : launch_tt<KS, 0, KMVP_FMM_KERNEL, 1>(TT, args, grid, stream);
+  return mode ? launch_tt<KS, 1, KMVP_FMM_KERNEL, 0>(TT, args, grid, stream)
+              : launch_tt<KS, 0, KMVP_FMM_KERNEL, 0>(TT, args, grid, stream);
 }
 
-hipError_t KMVP_FN(int KS, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
+hipError_t KMVP_FN(int KS, int mode, int TT, int online, const FastmmArgs& args, dim3 grid, hipStream_t stream,
                    const char** kernel_name) {
-  if (kernel_name) *kernel_name = "fastmm_kernel";
+  if (kernel_name) *kernel_name = online ? "fastmm_online_kernel" : "fastmm_kernel";
+  g_online = online;
   switch (KS) {
     case 1: return launch_mode<1>(mode, TT, args, grid, stream);
     case 2: return launch_mode<2>(mode, TT, args, grid, stream);

@@ -6,10 +6,12 @@
 namespace kmvp {
 
 // the part of the stage image the POINTS determine: per tile 32 rows of split-bf16 coordinates as in
-// pack_fast_sources_kernel, with a 1 in column 6 D + 6 (against the targets' -FMM_SHIFT); pad sources: |y'|^2 = +inf
+// pack_fast_sources_kernel, with a 1 in column 6 D + 6 (against the targets' -FMM_SHIFT) and in column 16 KS - 1 (always
+// free: 6 D + 7 is odd; against the targets' online shift -kop); pad sources: |y'|^2 = +inf.
+// dot != 0 (k = exp(<x,y>)): the rows hold -2 (y scale) uncentred and a zero norm, so that S = -2 scale <x, y>.
 __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float* __restrict__ centre,
                                         unsigned char* __restrict__ img, int64_t m, int64_t m_stages, int D, int KS,
-                                        int MODE, float scale) {
+                                        int MODE, float scale, int dot) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m_stages * fmm_stage_tiles(KS) * FAST_TILE) return;
   const int64_t stage = j / (fmm_stage_tiles(KS) * FAST_TILE);
@@ -22,8 +24,8 @@ __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float
   const __bf16 zero = (__bf16)0.f, one = (__bf16)1.f;
   double sq = 0.0;
   for (int d = 0; d < D; ++d) {
-    const float v = live ? (y[j * D + d] - centre[d]) * scale : 0.f;
-    sq += (double)v * (double)v;
+    const float v = live ? (dot ? y[j * D + d] * scale : (y[j * D + d] - centre[d]) * scale) : 0.f;
+    if (!dot) sq += (double)v * (double)v;
     __bf16 vh, vm, vl;
     fast_split3(v, vh, vm, vl);
     const __bf16 h2 = (__bf16)(-2.f * (float)vh), m2 = (__bf16)(-2.f * (float)vm), l2 = (__bf16)(-2.f * (float)vl);
@@ -44,6 +46,7 @@ __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float
   row[6 * D + 5] = one;
   row[6 * D + 6] = one;
   for (int k = 6 * D + 7; k < 16 * KS + 8; ++k) row[k] = zero;  // incl. the 16-byte row pad
+  row[16 * KS - 1] = one;
 }
 
 // target operands [n_pad / 32][KS][64 lanes] x 16 bytes: lane (r, h) of target tile t holds elements k = 16 ks + 8 h + j
@@ -51,15 +54,16 @@ __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float
 // split three ways into bf16, then 1, 1, 1, |x'|^2 h, m, l (accumulated in double, rounded once), -FMM_SHIFT, zeros.
 // One thread per (target, k-step, lane half).
 // (shift: FMM_SHIFT for the Gaussian, 0 for exp(-r), whose shift is applied after the square root)
+// dot != 0: uncentred, unscaled coordinates and a zero norm (see pack_fastmm_rows_kernel)
 __global__ void pack_fastmm_targets_kernel(const float* __restrict__ x, const float* __restrict__ centre,
                                            unsigned char* __restrict__ xop, int64_t n, int64_t n_pad, int D, int KS,
-                                           float scale, float shift) {
+                                           float scale, float shift, int dot) {
   const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= n_pad * KS * 2) return;
   const int64_t i = id / (2 * KS);
   const int ks = (int)((id / 2) % KS), h = (int)(id & 1);
   double sq = 0.0;
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < D && !dot; ++d) {
     const float v = i < n ? (x[i * D + d] - centre[d]) * scale : 0.f;
     sq += (double)v * (double)v;
   }
@@ -71,7 +75,7 @@ __global__ void pack_fastmm_targets_kernel(const float* __restrict__ x, const fl
     __bf16 e = (__bf16)0.f;
     if (k < 6 * D) {
       const int d = k / 6, role = k % 6;
-      const float v = i < n ? (x[i * D + d] - centre[d]) * scale : 0.f;
+      const float v = i < n ? (dot ? x[i * D + d] : (x[i * D + d] - centre[d]) * scale) : 0.f;
       __bf16 vh, vm, vl;
       fast_split3(v, vh, vm, vl);
       e = (role == 0 || role == 2 || role == 5) ? vh : ((role == 1 || role == 4) ? vm : vl);

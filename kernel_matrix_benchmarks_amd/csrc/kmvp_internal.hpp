@@ -74,10 +74,11 @@ hipError_t launch_fast_invdist(int D, int sig, int TT, const FastArgs& args, dim
 constexpr double FMM_PS_PER_TILE_16 = 180.0, FMM_PS_PER_TILE_32 = 225.0;
 constexpr double CMM_PS_PER_TILE_MAIN = 26.0, CMM_PS_PER_TILE_TT4 = 30.0, CMM_PS_PER_TILE_REST = 48.0;
 struct FastmmArgs;
-hipError_t launch_fastmm_gaussian(int KS, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
+// online != 0: per-target running shift (kmvp_fastmm.hpp "The shift"); the kernel then reports as fastmm_online_kernel
+hipError_t launch_fastmm_gaussian(int KS, int mode, int TT, int online, const FastmmArgs& args, dim3 grid, hipStream_t stream,
                                   const char** kernel_name);
 // exp(-r) on the same expansion, closest pairs recomputed exactly (5 <= D <= 64; D <= 4: the centred forms)
-hipError_t launch_fastmm_absexp(int KS, int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream,
+hipError_t launch_fastmm_absexp(int KS, int mode, int TT, int online, const FastmmArgs& args, dim3 grid, hipStream_t stream,
                                 const char** kernel_name);
 // tau = FMM_ABSEXP_KAPPA R^4 (R^2: scaled squared radius of the clouds): below it the error ~1e-7 R^2 of s would show
 // in 2^-sqrt(s) beyond 1e-6 -- sqrt(s) >= ln2 * 1e-7 R^2 / 2e-6 = 0.035 R^2; twice that for margin
@@ -85,7 +86,7 @@ constexpr float FMM_ABSEXP_KAPPA = 5.0e-3f;
 
 // the same second product on cfast_kernel's distances (kmvp_cfastmm.hpp): Gaussian and exp(-r), float32, D <= 4
 struct CfastmmArgs;
-hipError_t launch_cfastmm(int kernel, int mode, int TT, const CfastmmArgs& args, dim3 grid, hipStream_t stream,
+hipError_t launch_cfastmm(int kernel, int mode, int TT, int online, const CfastmmArgs& args, dim3 grid, hipStream_t stream,
                           const char** kernel_name);
 constexpr int CFMM_AUTO_MIN_COLS = 4;  // auto: from four columns on (1e5 points, four columns: 3.0 ms against 3.7 ms of the difference form)
 

@@ -33,7 +33,7 @@
 
 namespace kmvp {
 
-enum : int { K_GAUSSIAN = 0, K_ABSEXP = 1, K_INVDIST = 2 };
+enum : int { K_GAUSSIAN = 0, K_ABSEXP = 1, K_INVDIST = 2, K_EXPDOT = 3 };  // K_EXPDOT: host-side only (run_product)
 
 // signal mode of a launch
 enum : int {

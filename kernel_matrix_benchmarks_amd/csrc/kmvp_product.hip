@@ -146,16 +146,57 @@ __global__ void reduce_block_kernel(const double* __restrict__ part, double* __r
   sums[(int64_t)(e < Ek ? col0 + e : den_col) * n_pad + i] = v;
 }
 
-// out[i*E + e] = sums[e][i]  (/ sums[E][i] when normalised)
+// out[i*E + e] = sums[e][i]  (/ sums[E][i] when normalised).  kshift (exp(<x,y>), or nullptr): the sums of target i are
+// at the scale 2^-kshift[i] -- it cancels in normalised rows and is applied to plain ones here (+inf: no source at all).
 __global__ void finish_kernel(const double* __restrict__ sums, double* __restrict__ out, int64_t n,
-                              int64_t n_pad, int E, int normalise) {
+                              int64_t n_pad, int E, int normalise, const double* __restrict__ kshift) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double den = normalise ? sums[(int64_t)E * n_pad + i] : 1.0;
+  int back = 0;
+  bool none = false;
+  if (kshift && !normalise) {
+    const double k = kshift[i];
+    none = !(k < 1.0e300);
+    back = none ? 0 : (int)fmin(fmax(-k, -100000.0), 100000.0);
+  }
   for (int e = 0; e < E; ++e) {
     const double v = sums[(int64_t)e * n_pad + i];
-    out[i * E + e] = normalise ? v / den : v;
+    out[i * E + e] = normalise ? v / den : (none ? 0.0 : (back ? ldexp(v, back) : v));
   }
+}
+
+// exp(<x,y>) (fastmm_kernel with FastmmArgs::kexp): partial sums part[s][e][i] at the scale 2^-kexp[s][i].
+//   K_i = min_s kexp[s][i]  (the exponent of the row's largest term so far; +inf: segment s had no live source)
+//   sums[col][i] = sum_s part[s][e][i] 2^(K_i - kexp[s][i])        (every factor <= 1: nothing overflows)
+// Columns as in reduce_block_kernel (e < Ek -> col0 + e, the extra column -> den_col); kmin[i] = K_i.
+__global__ void reduce_shifted_kernel(const double* __restrict__ part, const float* __restrict__ kexp,
+                                      double* __restrict__ sums, double* __restrict__ kmin, int64_t n_pad, int NEk, int Ek,
+                                      int segments, int col0, int den_col) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (int64_t)NEk * n_pad) return;
+  const int e = (int)(q / n_pad);
+  const int64_t i = q % n_pad;
+  float K = INFINITY;
+  for (int s = 0; s < segments; ++s) K = fminf(K, kexp[(int64_t)s * n_pad + i]);
+  double v = 0.0;
+  for (int s = 0; s < segments; ++s) {
+    const float ks = kexp[(int64_t)s * n_pad + i];
+    if (ks < INFINITY) v += ldexp(part[((int64_t)s * NEk + e) * n_pad + i], (int)fmaxf(K - ks, -100000.f));
+  }
+  sums[(int64_t)(e < Ek ? col0 + e : den_col) * n_pad + i] = v;
+  if (e == 0) kmin[i] = (double)K;
+}
+
+// after the all-reduce(min) of the exponents over the ranks: this rank's sums move to the common scale 2^-kglobal
+__global__ void rescale_shifted_kernel(double* __restrict__ sums, const double* __restrict__ klocal,
+                                       const double* __restrict__ kglobal, int64_t n, int64_t n_pad, int NE) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (int64_t)NE * n) return;
+  const int64_t e = q / n, i = q % n;
+  const double kl = klocal[i], kg = kglobal[i];
+  double& v = sums[e * n_pad + i];
+  v = (kl < 1.0e300) ? ldexp(v, (int)fmax(kg - kl, -100000.0)) : 0.0;
 }
 
 // canon[e][i] = sums[e][i] for i < n: drops the path-specific padding before the all-reduce
@@ -176,11 +217,31 @@ __global__ void fill_kernel(double* p, int64_t n, double v) {
 // stream capture) records nothing.
 inline hipError_t mark(kmvp_ctx* c, int i) { return c->async_product ? hipSuccess : hipEventRecord(c->ev[i], c->stream); }
 
+// In-place all-reduce of `count` doubles on the device over the ranks of the attached exchange: ncclAllReduce on the
+// context's stream, or -- rehearsal transport (kmvp_comm_init_host) -- device -> host, the caller's callback (e.g. gloo),
+// host -> device: same buffer, same place in the stream, only the wire differs.
+int exchange_f64(kmvp_ctx* c, double* buf, int64_t count, int op) {
+  if (c->comm) {
+    ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat64, op == KMVP_OP_MIN ? ncclMin : ncclSum, c->comm,
+                                      c->stream);
+    if (r != ncclSuccess) return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    return KMVP_OK;
+  }
+  const size_t cnt = (size_t)count;
+  c->host_buf.resize(std::max<size_t>(cnt, 1));
+  HIP_TRY(c, hipMemcpyAsync(c->host_buf.data(), buf, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int hr = c->host_xchg(c->host_user, c->host_buf.data(), (int64_t)cnt, op);
+  if (hr != 0) return fail(c, KMVP_E_COMM, "host all-reduce callback failed with status " + std::to_string(hr));
+  HIP_TRY(c, hipMemcpyAsync(buf, c->host_buf.data(), cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  return KMVP_OK;
+}
+
 // Common tail of every path, after the path's own reduction has left sums[column][n_pad]
 // (fp64) in c->sums: one RCCL all-reduce over the source shards when a communicator is
 // attached, normalisation / transposition into (N,E), event bookkeeping, and the stream
 // synchronisation that makes the entry point synchronous (runner.py:138-140 times it).
-int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, int sig) {
+int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, int sig, const double* kshift = nullptr) {
   int rc;
   const double* sums = (const double*)c->sums.p;
   if (c->exchanges()) {  // also with world == 1: the one-GPU tests then run the real exchange path
@@ -193,29 +254,14 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
                        N, n_pad, NE);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, mark(c, 3));
-    if (c->comm) {
-      ncclResult_t r = g_rccl.AllReduce(c->xchg.p, c->xchg.p, (size_t)(NE * N), ncclFloat64, ncclSum, c->comm,
-                                        c->stream);
-      if (r != ncclSuccess)
-        return fail(c, KMVP_E_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
-    } else {
-      // rehearsal transport: device -> host, the caller's all-reduce (e.g. gloo), host -> device.  Same buffer, same
-      // canonical layout, same place in the stream as the RCCL call -- only the wire differs.
-      const size_t cnt = (size_t)(NE * N);
-      c->host_buf.resize(std::max<size_t>(cnt, 1));
-      HIP_TRY(c, hipMemcpyAsync(c->host_buf.data(), c->xchg.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      const int hr = c->host_xchg(c->host_user, c->host_buf.data(), (int64_t)cnt);
-      if (hr != 0) return fail(c, KMVP_E_COMM, "host all-reduce callback failed with status " + std::to_string(hr));
-      HIP_TRY(c, hipMemcpyAsync(c->xchg.p, c->host_buf.data(), cnt * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
+    if ((rc = exchange_f64(c, (double*)c->xchg.p, NE * N, KMVP_OP_SUM))) return rc;
     HIP_TRY(c, mark(c, 4));
     sums = (const double*)c->xchg.p;
     n_pad = N;
   }
   if ((rc = ensure(c, c->out, (size_t)std::max<int64_t>(N, 1) * E * sizeof(double)))) return rc;
   hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1))), dim3(256), 0, c->stream,
-                     sums, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0);
+                     sums, (double*)c->out.p, N, n_pad, E, sig == SIG_NORM ? 1 : 0, kshift);
   HIP_TRY(c, hipGetLastError());
   c->out_n = N;
   c->out_e = E;
@@ -229,6 +275,25 @@ int finish_product(kmvp_ctx* c, int64_t count, int64_t N, int64_t n_pad, int E, 
   return KMVP_OK;
 }
 
+
+// Tail of the exp(<x,y>) path: c->sums [NE][n_pad] at the per-target scale 2^-K_i with K in c->kshift [n_pad].  Sharded:
+// the ranks first agree on K (all-reduce MIN: the flash-attention (m, l, o) merge with m an integer exponent), move their
+// sums to it, and then take the common tail (all-reduce SUM, normalise).
+int finish_product_shifted(kmvp_ctx* c, int64_t N, int64_t n_pad, int E, int sig) {
+  const int NE = sig == SIG_NORM ? E + 1 : E;
+  int rc;
+  const double* kshift = (const double*)c->kshift.p;
+  if (c->exchanges()) {
+    if ((rc = ensure(c, c->xchgk, (size_t)std::max<int64_t>(N, 1) * sizeof(double)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->xchgk.p, c->kshift.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = exchange_f64(c, (double*)c->xchgk.p, N, KMVP_OP_MIN))) return rc;
+    hipLaunchKernelGGL(rescale_shifted_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream, (double*)c->sums.p,
+                       (const double*)c->kshift.p, (const double*)c->xchgk.p, N, n_pad, NE);
+    HIP_TRY(c, hipGetLastError());
+    kshift = (const double*)c->xchgk.p;
+  }
+  return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig, kshift);
+}
 
 // Epilogue of the paths with fp64 partials [segment][column][n_pad] in c->part.  Without a
 // communicator one fused launch does it; with one, the segments are summed into c->sums first and
@@ -586,7 +651,9 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
 
 // Gaussian products with several signal columns, both matrix products on the matrix cores (kmvp_fastmm.hpp): float32,
 // D <= 64, any E (blocks of up to 32 columns, the denominator of normalised rows being one more column).
-int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
+// dot: k = exp(<x,y>) -- the Gaussian instantiation on operands without norms (S = -log2(e) <x,y>), always with the
+// online shift, partial sums as (mantissa, exponent) pairs (FastmmArgs::kexp) and the shifted tail.
+int run_product_fastmm(kmvp_ctx* c, int kernel, int sig, bool dot = false) {
   const int D = c->D, E = c->E;
   const int NE = sig == SIG_NORM ? E + 1 : E;
   const int64_t N = c->N, M = c->M;
@@ -596,7 +663,8 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
   const int tt_max = KS <= FMM_MAX_KS_TWO_TILES ? 2 : 1;  // (four tiles: no faster, 256 VGPRs)
   const int TT = c->opt_fast_tiles > 0 ? std::min(c->opt_fast_tiles, tt_max) : (small ? 1 : tt_max);
   const int64_t SB = fmm_stage_bytes(KS, MODE);
-  const float scale = scale_for<float>(kernel);
+  // dot: the source rows hold -2 (y scale), so scale = log2(e) / 2 gives S = -log2(e) <x, y>
+  const float scale = dot ? 0.72134752044448170f : scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   const int64_t tile = (int64_t)FAST_TILE * TT * WAVES_PER_BLOCK;
   const int64_t n_pad = round_up(N, tile);
@@ -604,6 +672,10 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
   const int64_t m_tiles = (M + FAST_TILE - 1) / FAST_TILE;
   const int64_t m_stages = (m_tiles + fmm_stage_tiles(KS) - 1) / fmm_stage_tiles(KS);
   const int nb_max = std::min(NE, FMM_MAX_COLS);
+  // the fixed shift 2^15 assumes every target has a source at distance ~0, i.e. targets == sources (also when the
+  // sources are sharded: the all-reduced row then contains the self term); otherwise the per-target running shift
+  const int online = (dot || !(c->same_points || c->opt_same_global)) ? 1 : 0;
+  const int layout_kernel = dot ? K_EXPDOT : kernel;
   int rc;
 
   // (the kernel's time does not depend on the segment count between 8 and 48 at 1e5 points, the fp64 partial sums --
@@ -614,7 +686,7 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
   if (tile_blocks * segments > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
 
   const int layout_T = TT + 16 * MODE;
-  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
+  const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != layout_kernel ||
                          c->packed_layout != LAYOUT_FASTMM || c->packed_T != layout_T;
   const bool one_block = NE <= FMM_MAX_COLS;
   const bool sig_stale = pts_stale || !one_block || c->packed_signal_ver != c->signal_ver || c->packed_sig != sig;
@@ -627,22 +699,27 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
     if ((rc = ensure(c, c->rec, (size_t)m_stages * SB))) return rc;
     hipLaunchKernelGGL(pack_fastmm_targets_kernel, dim3(blocks_for(n_pad * KS * 2)), dim3(256), 0, c->stream, x_raw,
                        centre, (unsigned char*)c->xs.p, N, n_pad, D, KS, scale,
-                       kernel == K_GAUSSIAN ? (float)FMM_SHIFT : 0.f);
+                       kernel == K_GAUSSIAN ? (float)FMM_SHIFT : 0.f, dot ? 1 : 0);
     hipLaunchKernelGGL(pack_fastmm_rows_kernel, dim3(blocks_for(m_stages * fmm_stage_tiles(KS) * FAST_TILE)), dim3(256), 0,
                        c->stream, (const float*)c->y_raw.p, centre, (unsigned char*)c->rec.p, M, m_stages, D, KS, MODE,
-                       scale);
+                       scale, dot ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
   }
   c->packed_points_ver = c->points_ver;
-  c->packed_kernel = kernel;
+  c->packed_kernel = layout_kernel;
   c->packed_layout = LAYOUT_FASTMM;
   c->packed_T = layout_T;
   c->packed_signal_ver = c->signal_ver;
   c->packed_sig = one_block ? sig : -1;
 
   if ((rc = ensure(c, c->part, (size_t)segments * nb_max * n_pad * sizeof(double)))) return rc;
-  if (!one_block && (rc = ensure(c, c->sums, (size_t)NE * n_pad * sizeof(double)))) return rc;
+  if ((!one_block || dot) && (rc = ensure(c, c->sums, (size_t)NE * n_pad * sizeof(double)))) return rc;
+  if (dot) {
+    if ((rc = ensure(c, c->kexp, (size_t)segments * n_pad * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->kshift, (size_t)n_pad * sizeof(double)))) return rc;
+  }
   FastmmArgs a;
+  a.kexp = dot ? (float*)c->kexp.p : nullptr;
   a.xop = (const unsigned char*)c->xs.p;
   a.img = (const unsigned char*)c->rec.p;
   a.unscale = unscale;
@@ -677,11 +754,18 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
       HIP_TRY(c, hipGetLastError());
     }
     a.NE = nb;
-    hipError_t le = kernel == K_ABSEXP ? launch_fastmm_absexp(KS, MODE, TT, a, grid, c->stream, &c->last_kernel_name)
-                                       : launch_fastmm_gaussian(KS, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
+    hipError_t le = kernel == K_ABSEXP ? launch_fastmm_absexp(KS, MODE, TT, online, a, grid, c->stream, &c->last_kernel_name)
+                                       : launch_fastmm_gaussian(KS, MODE, TT, online, a, grid, c->stream, &c->last_kernel_name);
     if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "no fastmm_kernel for this dimension / tile count");
     HIP_TRY(c, le);
-    if (!one_block) {
+    if (dot) {
+      // (every pass runs the same distances in the same order: its exponents are the previous pass's, bit for bit)
+      const int Ek = std::max(0, std::min(nb, E - col0));
+      hipLaunchKernelGGL(reduce_shifted_kernel, dim3(blocks_for((int64_t)nb * n_pad)), dim3(256), 0, c->stream,
+                         (const double*)c->part.p, (const float*)c->kexp.p, (double*)c->sums.p, (double*)c->kshift.p, n_pad,
+                         nb, Ek, segments, col0, E);
+      HIP_TRY(c, hipGetLastError());
+    } else if (!one_block) {
       const int Ek = std::min(nb, E - col0);  // signal columns of the block; the one beyond them is the denominator
       hipLaunchKernelGGL(reduce_block_kernel, dim3(blocks_for((int64_t)nb * n_pad)), dim3(256), 0, c->stream,
                          (const double*)c->part.p, (double*)c->sums.p, n_pad, nb, Ek, segments, col0, E);
@@ -689,6 +773,7 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig) {
     }
   }
   HIP_TRY(c, mark(c, 1));
+  if (dot) return finish_product_shifted(c, N, n_pad, E, sig);
   if (one_block) return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
   return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
 }
@@ -814,6 +899,7 @@ int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
   const int64_t m_alloc = m_stages * CF_GROUP;
   const int nb_max = std::min(NE, FMM_MAX_COLS);
   if (c->m_total > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "more than 2^31 sources");
+  const int online = (c->same_points || c->opt_same_global) ? 0 : 1;  // see run_product_fastmm
   int rc;
 
   int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small, 2 << 20, 4096);
@@ -874,7 +960,7 @@ int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
       HIP_TRY(c, hipGetLastError());
     }
     a.NE = nb;
-    hipError_t le = launch_cfastmm(kernel, MODE, TT, a, grid, c->stream, &c->last_kernel_name);
+    hipError_t le = launch_cfastmm(kernel, MODE, TT, online, a, grid, c->stream, &c->last_kernel_name);
     if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "no cfastmm_kernel for this kernel / tile count");
     HIP_TRY(c, le);
     if (!one_block) {
@@ -1702,6 +1788,12 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     HIP_TRY(c, mark(c, 1));
     c->last_kernel_name = "none";
     if (c->density && normalise) {  // every rank takes the all-ones shortcut below: no exchange
+    } else if (kernel == K_EXPDOT) {  // ... and its (absent) exponents: +inf loses every all-reduce(min)
+      if ((rc = ensure(c, c->kshift, (size_t)c->N * sizeof(double)))) return rc;
+      hipLaunchKernelGGL(fill_kernel, dim3(blocks_for(c->N)), dim3(256), 0, c->stream, (double*)c->kshift.p, c->N,
+                         (double)INFINITY);
+      HIP_TRY(c, hipGetLastError());
+      return finish_product_shifted(c, c->N, c->N, E, sig0);
     } else {
       return finish_product(c, NE * c->N, c->N, c->N, E, sig0);
     }
@@ -1736,6 +1828,13 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
     return KMVP_OK;
   }
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
+  if (kernel == K_EXPDOT) {
+    // k = exp(<x,y>) (include/kmvp.h kmvp_expdot): float32 on fastmm_kernel's matrix-core path only
+    if (c->dtype != KMVP_F32 || c->D > FMM_MAX_D)
+      return fail(c, KMVP_E_UNSUPPORTED, "exp(<x,y>) is built for float32 and D <= 64 (other cases: the plugin's Gaussian identity)");
+    if (c->density) return fail(c, KMVP_E_UNSUPPORTED, "exp(<x,y>): pass a signal of ones for density estimation");
+    return run_product_fastmm(c, K_GAUSSIAN, sig, true);
+  }
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);
   if (c->dtype == KMVP_F32 && kernel == K_GAUSSIAN && !c->density && (c->E > 1 || c->D > FAST_MAX_D) &&
       c->centre_ver == c->points_ver && (c->opt_fast < 0 || c->opt_fast == 1 || c->opt_fast == 3)) {

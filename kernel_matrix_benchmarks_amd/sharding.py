@@ -79,8 +79,9 @@ class Communicator:
         self.rank = int(rank)
         self.world = int(world)
         self._broadcast = broadcast_bytes
-        # REHEARSAL only (several ranks on ONE GPU, where RCCL refuses to form a communicator): a callable that sums
-        # a float64 numpy array in place over the ranks; the library then stages its exchange through host memory
+        # REHEARSAL only (several ranks on ONE GPU, where RCCL refuses to form a communicator): a callable
+        # (array, op) that reduces a float64 numpy array in place over the ranks (op 0: sum, 1: min); the library
+        # then stages its exchange through host memory
         # (include/kmvp.h kmvp_comm_init_host) instead of calling ncclAllReduce
         self._host_allreduce = host_allreduce
 
@@ -119,8 +120,8 @@ def torch_gloo_communicator(exchange="rccl"):
     if exchange == "host":
         import torch
 
-        def host(array):
-            dist.all_reduce(torch.from_numpy(array))  # in place, float64, sum
+        def host(array, op):
+            dist.all_reduce(torch.from_numpy(array), op=dist.ReduceOp.MIN if op == 1 else dist.ReduceOp.SUM)  # in place
 
     elif exchange != "rccl":
         raise ValueError("exchange must be 'rccl' or 'host'")

@@ -68,6 +68,30 @@ def main():
         report.append({"kernel": kernel, "precision": str(precision), "n": n, "shard": [lo, hi], "rel_err": e,
                        "device_kernel": meta["device_kernel"]})
 
+    # exp(<x,y>) sharded: (mantissa, exponent) partial sums, all-reduce(min) of the exponents, then the sum
+    rs = np.random.RandomState(5)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    y, x, b = f32(rs.randn(3001, 8) * 3.5), f32(rs.randn(500, 8)), f32(rs.randn(3001, 3))
+    # (sources ordered by norm: the ranks' exponents then differ by hundreds)
+    y = y[np.argsort(np.sum(y * y, axis=1))]
+    for normalize in (True, False):
+        algo = MI355XProduct(kernel="exp-dot", dimension=8, normalize_rows=normalize, precision="float32", device=0, comm=comm)
+        try:
+            algo.prepare_data(source_points=y, target_points=x, same_points=False)
+            algo.fit()
+            algo.prepare_query(source_signal=b)
+            algo.query()
+            got = algo.get_result()
+            meta = algo.get_additional()
+        finally:
+            algo.done()
+        want = kmvp_oracle.exp_dot_product(source_points=y, target_points=x, source_signal=b, normalize_rows=normalize)
+        scale = np.max(np.abs(want), axis=1, keepdims=True)
+        e = float(np.max(np.abs(got - want) / scale))
+        assert meta["device_kernel"] == "fastmm_online_kernel" and meta["rccl_ranks"] == world, meta
+        assert np.isfinite(got).all() and e <= 1e-4, ("exp-dot", normalize, e)
+        report.append({"kernel": "exp-dot", "normalize": normalize, "rel_err": e, "device_kernel": meta["device_kernel"]})
+
     # sharded solvers: replicated Krylov vectors, operator summed over the ranks in every iteration
     for kernel, n, rtol in (("gaussian", 3000, 1e-6), ("inverse-distance", 1500, 1e-8)):
         y, b = kmvp_oracle.uniform_cube(n, 3)
