@@ -517,7 +517,7 @@ def roofline_of(W, kname, k_ms, world=1):
                                    "2 (D + E + 1) matrix flop per pair (distances + P [b | 1], SURVEY 8d) vs the dense "
                                    "bf16 MFMA peak; the transcendental rate bounds it equally (one sqrt + one exp2 per pair)")
     else:
-        bound, fpp, peak, basis = ROOF.get(kname.replace("_online", ""), ROOF["lowd_kernel"])
+        bound, fpp, peak, basis = ROOF.get(kname, ROOF["lowd_kernel"])
     achieved = fpp * shard_pairs / (k_ms * 1e-3) / 1e12
     cfg = W.cfg
     tag = {"2": f"{'gaussian' if W.kernel == 'gaussian' else W.kernel}_1e6_{'f32' if W.precision == 'float32' else 'f64'}",

@@ -85,17 +85,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
 #pragma unroll
     for (int q = 0; q < NOUT; ++q) accd[tt][q] = 0.0;
   }
-  auto fold = [&]() {  // as in fastmm_kernel
+  auto fold_one = [&](int tt) {  // as in fastmm_kernel
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-      for (int q = 0; q < NOUT; ++q) {
-        if constexpr (MODE == 0) accd[tt][q] += (double)acc[tt][q] + (double)acc[tt][q + 8];
-        else accd[tt][q] += (double)acc[tt][q];
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
+    for (int q = 0; q < NOUT; ++q) {
+      if constexpr (MODE == 0) accd[tt][q] += (double)acc[tt][q] + (double)acc[tt][q + 8];
+      else accd[tt][q] += (double)acc[tt][q];
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
+  };
+  auto fold = [&]() {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) fold_one(tt);
   };
 
   const int64_t s_begin = (int64_t)seg * a.seg_stages;
@@ -197,9 +198,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
           if constexpr (KERNEL == K_ABSEXP) m = __builtin_amdgcn_sqrtf(fmaxf(m, 0.f));
           else m = fmaxf(m, 0.f);
           const bool first = s == s_begin && rt == 0;
-          const bool need = (first || m < kop[tt]) && m < 3.0e38f;
+          const bool need = (first || m < kop[tt] - 0.5f) && m < 3.0e38f;  // (hysteresis: T up to 2^15.5 is still an f16 number)
           if (__any(need)) {  // rare
-            fold();
+            fold_one(tt);
             if (need) {
               const float kn = floorf(m);
               const int di = (int)(kop[tt] - kn);  // >= 0 except at the first tile (nothing accumulated yet)

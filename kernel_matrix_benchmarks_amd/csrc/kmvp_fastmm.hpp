@@ -9,7 +9,7 @@
 //
 //   S  (32 sources x 32 targets) = Y~ X~^T          KS bf16 MFMAs   (operands as in kmvp_fast.hpp, plus one column
 //                                                                    that subtracts FMM_SHIFT: T = 2^15 exp(-s));
-//                                                                    D <= 64, KS = ceil((6 D + 7) / 16) <= 25
+//                                                                    D <= 64, KS = ceil((6 D + 9) / 16) <= 25
 //   T  = exp2(-S)                                   16 v_exp_f32 per lane: the one transcendental per PAIR
 //                                                   (exp(-r), KERNEL = K_ABSEXP: exp2(15 - sqrt(S)) without the shift
 //                                                   column, closest pairs recomputed exactly: see the kernel)
@@ -37,9 +37,10 @@
 // f16 floor (rows 3.8 / 4.5 away came out 5e-2 off / NaN).  ONLINE = 1 carries a per-TARGET integer shift
 // kop, the flash-attention recurrence with the running maximum rounded to an integer power of two:
 //     T = 2^(15 + kop) k ,   kop = floor(log2 of 1 / (largest k seen so far for this target))
-//  * Gaussian / exp(<x,y>): the shift rides in the MFMA operands -- column 16 KS - 1 of the target row holds -kop
-//    (a bf16-exact integer: kop is rounded DOWN to 8 significant bits), the source rows hold 1 there -- so the
-//    pair loop pays only the running minimum of S (8 v_min3 + one v_permlane32_swap per tile);
+//  * Gaussian / exp(<x,y>): the shift rides in the MFMA operands -- columns 16 KS - 1 and 16 KS - 2 of the target row
+//    hold -k_hi and -k_lo (kop = k_hi + k_lo, k_hi a multiple of 128, |k_lo| < 128: both exact in bf16, |kop| up
+//    to 32000, i.e. logits up to 2.2e4), the source rows hold 1 there -- so the pair loop pays only the running
+//    minimum of S (8 v_min3 + one v_permlane32_swap per tile);
 //  * exp(-r): T = exp2(15 + kop - sqrt(S)), the per-lane constant replaces the literal 15 (free);
 //  * when a tile would exceed 2^15 (or at a wave's first tile) the fp32 accumulator is folded into the fp64 sums,
 //    these are rescaled by 2^(kop_new - kop_old) <= 1 (exact), the tile's S is shifted and the operand patched:
@@ -67,9 +68,11 @@ constexpr int FMM_MAX_KS_TWO_TILES = 4;  // two target tiles per wave while the 
 // source tiles per LDS stage: four while a stage stays below ~30 KiB, two up to K = 144, one beyond
 __host__ __device__ constexpr int fmm_stage_tiles(int KS) { return KS <= 4 ? 4 : (KS <= 9 ? 2 : 1); }
 constexpr int FMM_SHIFT = 15;        // T = 2^15 exp(-s) <= 32768 < 65504: small kernel values stay normal f16 numbers
+constexpr float FMM_MAX_ONLINE_SHIFT = 32000.f;  // |kop|: what the two bf16 operand columns hold exactly (k_hi = 128 j, |j| <= 255)
 constexpr int FMM_MAX_COLS = 32;
 
-__host__ __device__ constexpr int fmm_ksteps(int D) { return (6 * D + 7 + 15) / 16; }
+// K = 6 D + 7 columns (kmvp_fastmm_pack.hpp) + the two columns of the online shift at 16 KS - 2, 16 KS - 1
+__host__ __device__ constexpr int fmm_ksteps(int D) { return (6 * D + 9 + 15) / 16; }
 __host__ __device__ constexpr int fmm_row_bytes(int KS) { return KS * 32 + 16; }
 __host__ __device__ constexpr int fmm_sig_bytes(int MODE) { return MODE ? 4096 : 2048; }
 __host__ __device__ constexpr int fmm_tile_bytes(int KS, int MODE) { return FAST_TILE * fmm_row_bytes(KS) + fmm_sig_bytes(MODE); }
@@ -119,14 +122,6 @@ template <int KERNEL>
 __device__ __forceinline__ float fmm_tval(float S, float sh) {
   if constexpr (KERNEL == K_GAUSSIAN) return kexp2(-S);
   else return kexp2(sh - __builtin_amdgcn_sqrtf(__builtin_fabsf(S)));
-}
-
-// largest bf16-representable value <= v (v an integer-valued float): the shift that goes into a bf16 operand
-__device__ __forceinline__ float fmm_bf16_floor(float v) {
-  const unsigned u = (unsigned)__float_as_int(v);
-  unsigned t = u & 0xffff0000u;
-  if ((int)u < 0 && (u & 0xffffu)) t += 0x10000u;  // negative: towards -inf
-  return __int_as_float((int)t);
 }
 
 // min over the two lane halves (lanes l and l ^ 32 hold the two halves of one target's sources): one VALU swap
@@ -190,17 +185,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
   }
   // rows of the accumulator registers: register 4g + j holds row 8g + 4h + j.  MODE 0: rows e (g < 2) and e + 16
   // (g + 2) are the two halves of column e; MODE 1: row = column.
+  auto fold_one = [&](int tt) {
+#pragma unroll
+    for (int q = 0; q < NOUT; ++q) {
+      if constexpr (MODE == 0) accd[tt][q] += (double)acc[tt][q] + (double)acc[tt][q + 8];
+      else accd[tt][q] += (double)acc[tt][q];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
+  };
   auto fold = [&]() {
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-      for (int q = 0; q < NOUT; ++q) {
-        if constexpr (MODE == 0) accd[tt][q] += (double)acc[tt][q] + (double)acc[tt][q + 8];
-        else accd[tt][q] += (double)acc[tt][q];
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[tt][q] = 0.f;
-    }
+    for (int tt = 0; tt < TT; ++tt) fold_one(tt);
   };
 
   const int64_t s_begin = (int64_t)seg * a.seg_stages;
@@ -291,13 +287,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
           float m = fmm_min_halves(dmin);
           if constexpr (KERNEL == K_ABSEXP) m = __builtin_amdgcn_sqrtf(fmaxf(m, 0.f));
           const bool first = s == s_begin && q == 0;
-          const bool need = (first || (KERNEL == K_ABSEXP ? m < kop[tt] : m < -(float)FMM_SHIFT)) && m < 3.0e38f;
+          // (half a binade of hysteresis: T up to 2^15.5 < 65504 is still an f16 number, and the rounding noise of s at
+          // nearly coincident points must not lower the shift of every such target by one)
+          const bool need = (first || (KERNEL == K_ABSEXP ? m < kop[tt] - 0.5f : m < -((float)FMM_SHIFT + 0.5f))) && m < 3.0e38f;
           if (__any(need)) {  // rare: see the header
-            fold();
+            fold_one(tt);  // (this tile's accumulator only: a target's sums do not depend on what else its wave owns)
             if (need) {
               float kn;
               if constexpr (KERNEL == K_ABSEXP) kn = floorf(m);
-              else kn = fmm_bf16_floor(kop[tt] + floorf(m + (float)FMM_SHIFT));
+              else kn = fminf(fmaxf(kop[tt] + floorf(m + (float)FMM_SHIFT), -FMM_MAX_ONLINE_SHIFT), FMM_MAX_ONLINE_SHIFT);
               const float delta = kop[tt] - kn;  // >= 0 except at the first tile
               if constexpr (KERNEL != K_ABSEXP) {
 #pragma unroll
@@ -306,7 +304,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fastmm_kernel(const FastmmArgs 
 #pragma unroll
                   for (int qq = 0; qq < 16; ++qq) dn[tt][qq] += delta;
                 }
-                if (h == 1) xb[tt][KS - 1][7] = (__bf16)(-kn);
+                // kn = k_hi + k_lo, both exact in bf16 and of kn's sign (no cancellation between the two columns): k_hi a
+                // multiple of 128 (8 significant bits up to 32640), |k_lo| < 128
+                const float k_hi = 128.f * truncf(kn * 0.0078125f);
+                if (h == 1) {
+                  xb[tt][KS - 1][7] = (__bf16)(-k_hi);
+                  xb[tt][KS - 1][6] = (__bf16)(k_hi - kn);
+                }
               }
               const int di = (int)delta;
 #pragma unroll

@@ -6,8 +6,8 @@
 namespace kmvp {
 
 // the part of the stage image the POINTS determine: per tile 32 rows of split-bf16 coordinates as in
-// pack_fast_sources_kernel, with a 1 in column 6 D + 6 (against the targets' -FMM_SHIFT) and in column 16 KS - 1 (always
-// free: 6 D + 7 is odd; against the targets' online shift -kop); pad sources: |y'|^2 = +inf.
+// pack_fast_sources_kernel, with a 1 in column 6 D + 6 (against the targets' -FMM_SHIFT) and in columns 16 KS - 2,
+// 16 KS - 1 (free by fmm_ksteps; against the two pieces of the targets' online shift); pad sources: |y'|^2 = +inf.
 // dot != 0 (k = exp(<x,y>)): the rows hold -2 (y scale) uncentred and a zero norm, so that S = -2 scale <x, y>.
 __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float* __restrict__ centre,
                                         unsigned char* __restrict__ img, int64_t m, int64_t m_stages, int D, int KS,
@@ -47,6 +47,7 @@ __global__ void pack_fastmm_rows_kernel(const float* __restrict__ y, const float
   row[6 * D + 6] = one;
   for (int k = 6 * D + 7; k < 16 * KS + 8; ++k) row[k] = zero;  // incl. the 16-byte row pad
   row[16 * KS - 1] = one;
+  row[16 * KS - 2] = one;
 }
 
 // target operands [n_pad / 32][KS][64 lanes] x 16 bytes: lane (r, h) of target tile t holds elements k = 16 ks + 8 h + j

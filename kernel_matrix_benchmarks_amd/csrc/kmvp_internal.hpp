@@ -74,7 +74,7 @@ hipError_t launch_fast_invdist(int D, int sig, int TT, const FastArgs& args, dim
 constexpr double FMM_PS_PER_TILE_16 = 180.0, FMM_PS_PER_TILE_32 = 225.0;
 constexpr double CMM_PS_PER_TILE_MAIN = 26.0, CMM_PS_PER_TILE_TT4 = 30.0, CMM_PS_PER_TILE_REST = 48.0;
 struct FastmmArgs;
-// online != 0: per-target running shift (kmvp_fastmm.hpp "The shift"); the kernel then reports as fastmm_online_kernel
+// online != 0: per-target running shift (kmvp_fastmm.hpp "The shift")
 hipError_t launch_fastmm_gaussian(int KS, int mode, int TT, int online, const FastmmArgs& args, dim3 grid, hipStream_t stream,
                                   const char** kernel_name);
 // exp(-r) on the same expansion, closest pairs recomputed exactly (5 <= D <= 64; D <= 4: the centred forms)

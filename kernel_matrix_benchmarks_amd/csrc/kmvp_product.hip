@@ -773,6 +773,8 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig, bool dot = false) {
     }
   }
   HIP_TRY(c, mark(c, 1));
+  if (dot) c->note = "exp(<x,y>): fastmm_kernel with the per-target online shift, (mantissa, exponent) partial sums";
+  else if (online) c->note = "fastmm_kernel with the per-target online shift (targets != sources)";
   if (dot) return finish_product_shifted(c, N, n_pad, E, sig);
   if (one_block) return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
   return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
@@ -971,6 +973,7 @@ int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
     }
   }
   HIP_TRY(c, mark(c, 1));
+  if (online) c->note = "cfastmm_kernel with the per-target online shift (targets != sources)";
   if (one_block) return reduce_and_finish(c, segments, NE, N, n_pad, E, sig);
   return finish_product(c, (int64_t)NE * n_pad, N, n_pad, E, sig);
 }

@@ -112,10 +112,10 @@ def test_float16_is_at_least_as_accurate_as_the_references_float16(case, expecte
 def test_exp_dot_attention_matches_direct_evaluation():
     """k(x, y) = exp(<x, y>) (README.md:51-59; PARITY UNPINNED: no reference plugin implements it) against a direct
     float64 evaluation: softmax attention (row-normalised, E value channels), plain products, densities; float32 / float16
-    at D <= 64 on the native online-max kernel (fastmm_online_kernel), float64 and bfloat16 through the Gaussian identity;
+    at D <= 64 on the native online-max kernel (fastmm_kernel, ONLINE = 1), float64 and bfloat16 through the Gaussian identity;
     targets != sources; key norms spanning |y|^2/2 up to ~60."""
     rs = np.random.RandomState(99)
-    native = ("fastmm_online_kernel",)
+    native = ("fastmm_kernel",)
     shapes = [(3, 40000, 40000, 4, "float32", 1.0, native), (16, 700, 900, 8, "float32", 1.0, native),
               (16, 700, 900, 8, np.float64, 2.5, None), (64, 1024, 2048, 64, "float32", 0.35, native),
               (64, 1024, 2048, 64, "bfloat16", 0.35, None), (3, 500, 300, 1, "float16", 1.0, native)]
@@ -200,7 +200,7 @@ def test_exp_dot_native_kernel_has_no_range_limit():
                 algo.prepare_query(source_signal=b)
                 algo.query()
                 got = algo.get_result()
-                assert algo.device_kernel == "fastmm_online_kernel"
+                assert algo.device_kernel == "fastmm_kernel" and "online shift" in algo.get_additional()["dispatch_note"]
             finally:
                 algo.done()
             want = kmvp_oracle.exp_dot_product(source_points=y, target_points=x, source_signal=b, normalize_rows=norm)
@@ -213,7 +213,9 @@ def test_exp_dot_native_kernel_has_no_range_limit():
             else:
                 fin = np.isfinite(want).all(axis=1)
                 assert np.array_equal(np.isfinite(got).all(axis=1), fin), "plain product: inf rows differ from numpy's"
-                rowscale = np.max(np.abs(want[fin]), axis=1, keepdims=True)
+                # a row's yardstick is sum_j k |b_j|: two large terms of opposite sign may cancel in the row itself
+                mass = kmvp_oracle.exp_dot_product(source_points=y, target_points=x, source_signal=np.abs(b))
+                rowscale = np.max(mass[fin], axis=1, keepdims=True)
                 assert np.max(np.abs(got[fin] - want[fin]) / rowscale) <= tol, (D, norm, tol)
         print(f"exp-dot native D={D}: logits in [{logits.min():.0f}, {logits.max():.0f}], |y|^2/2 up to {np.max(np.sum(y*y,1))/2:.0f}")
     # beyond float64: logits ~ 2000.  softmax finite and right, plain product inf like numpy
@@ -248,7 +250,7 @@ def test_targets_far_from_every_source_keep_float32_accuracy():
     pieces.  With ONE global shift a target 4-5 away from every source had its whole row at or below the f16 floor (5e-2
     off, NaN rows when normalised).  Targets != sources now run the per-target online shift: disjoint clouds, targets
     offset by 4.2 / 4.8 / 5.5 / 9 along x, Gaussian and exp(-r), plain and normalised, inside the radius rule
-    (fastmm_online_kernel), outside it and exp(-r) (cfastmm_online_kernel), exp(-r) at D = 6 (fastmm_online_kernel);
+    (fastmm_kernel, ONLINE = 1), outside it and exp(-r) (cfastmm_kernel, ONLINE = 1), exp(-r) at D = 6 (fastmm_kernel);
     against the float64 oracle under the float32 rule of this file."""
     rs = np.random.RandomState(77)
     seen = set()
@@ -256,27 +258,32 @@ def test_targets_far_from_every_source_keep_float32_accuracy():
                            ("gaussian", 2, 0.2)):
         M, E = 6000, 8
         y = rs.rand(M, D) * box
-        offs = np.array([4.2, 4.8, 5.5, 9.0] if kernel == "gaussian" else [4.2, 30.0, 60.0, 95.0])
+        # (exp(-80) = 1.8e-35 is still a normal float32; beyond ~87 the float32 kernels flush where numpy denormalises)
+        offs = np.array([4.2, 4.8, 5.5, 9.0] if kernel == "gaussian" else [4.2, 20.0, 45.0, 80.0])
         x = rs.rand(400, D) * box
-        x[:, 0] += np.repeat(offs, 100) * (box if kernel == "gaussian" and box < 1 else 1.0)
-        if box < 1 and kernel == "gaussian":
-            x[:, 0] = rs.rand(400) * box + np.repeat([1.3, 1.6, 2.0, 2.4], 100)  # stay inside the radius rule: s up to ~6
+        x[:, 0] += np.repeat(offs, 100)
+        if box < 1:  # stay inside the radius rule (squared half-diagonal <= 8 / log2(e)): the expanded forms take it
+            x[:, 0] = rs.rand(400) * box + np.repeat([1.3, 1.6, 2.0, 2.4], 100)
         b = rs.randn(M, E)
         for norm in (False, True):
             want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b, normalize_rows=norm)
             ref32 = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b, normalize_rows=norm,
                                         precision=np.float32)
             got, extra = run_plugin(dict(kernel=kernel, D=D, normalize_rows=norm), y, x, b, "float32")
+            assert "online shift" in extra["dispatch_note"] or extra["device_kernel"] not in ("fastmm_kernel", "cfastmm_kernel"), extra
             seen.add(extra["device_kernel"])
-            # row by row: every group of targets has its own scale (e^-17 ... e^-80)
-            fin = np.isfinite(want).all(axis=1) & (np.max(np.abs(want), axis=1) > 0)
+            # row by row: every group of targets has its own scale (e^-17 ... e^-80); a row's yardstick is sum_j k |b_j|
+            mass = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=np.abs(b))
+            if norm:
+                mass = mass / kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=np.ones((M, 1)))
+            fin = np.isfinite(want).all(axis=1) & (np.max(mass, axis=1) > 0)
             assert np.isfinite(got[fin]).all(), (kernel, D, box, norm, extra["device_kernel"])
-            scale = np.max(np.abs(want[fin]), axis=1, keepdims=True)
+            scale = np.max(mass[fin], axis=1, keepdims=True)
             err = np.max(np.abs(got[fin] - want[fin]) / scale)
             ok32 = fin & np.isfinite(ref32).all(axis=1)
-            err32 = np.max(np.abs(ref32[ok32] - want[ok32]) / np.max(np.abs(want[ok32]), axis=1, keepdims=True)) if ok32.any() else 0.0
+            err32 = np.max(np.abs(ref32[ok32] - want[ok32]) / np.max(mass[ok32], axis=1, keepdims=True)) if ok32.any() else 0.0
             assert err <= max(TOL32, 2 * err32), (kernel, D, box, norm, extra["device_kernel"], err, err32)
-    assert {"fastmm_online_kernel", "cfastmm_online_kernel"} <= seen, seen
+    assert {"fastmm_kernel", "cfastmm_kernel"} <= seen, seen
 
 
 LOW_D_E1 = [c for c in CASES if c["D"] <= 39 and (c["E"] == 1 or c["density_estimation"])]
@@ -419,9 +426,14 @@ def test_fastmm_kernel_column_blocks_and_ragged_sizes(D, E, norm):
     finally:
         algo.done()
     want = kmvp_oracle.product(kernel="gaussian", source_points=y, target_points=x, source_signal=b, normalize_rows=norm)
+    ref32 = kmvp_oracle.product(kernel="gaussian", source_points=y, target_points=x, source_signal=b, normalize_rows=norm,
+                                precision=np.float32)
     assert got.shape == (n, E)
     col_err = np.abs(got - want).max(axis=0) / np.abs(want).max(axis=0)
-    assert col_err.max() <= TOL32, col_err
+    # per column, the rule of this file: the float32 tolerance or twice the error of the reference's own float32 arithmetic
+    # (columns whose 2051 terms cancel to a hundredth of their mass show every rounding a hundred times larger)
+    col_tol = np.maximum(TOL32, 2 * np.abs(ref32 - want).max(axis=0) / np.abs(want).max(axis=0))
+    assert (col_err <= col_tol).all(), (col_err, col_tol)
     assert np.array_equal(got2, 2.0 * got)  # powers of two go through the column scales exactly
 
 
