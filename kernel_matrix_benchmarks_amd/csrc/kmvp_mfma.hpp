@@ -88,6 +88,33 @@ __device__ __forceinline__ float mfma_kval(float s) {
   }
 }
 
+// The same in two stages for the rotated pipeline (mfma_pipe_kernel VAR bit 2): stage 1 maps s to the argument of the last
+// transcendental IN PLACE (exp(-r): r = sqrt|s|; the others: s), stage 2 is that transcendental.  A whole scheduling region
+// lies between the two, so the second never waits for the first.
+template <int KERNEL>
+__device__ __forceinline__ float mfma_kval_stage1(float s) {
+  if constexpr (KERNEL == K_ABSEXP) return __builtin_amdgcn_sqrtf(__builtin_fabsf(s));
+  else return s;
+}
+template <int KERNEL>
+__device__ __forceinline__ float mfma_kval_stage2(float u) {
+  if constexpr (KERNEL == K_GAUSSIAN) return kexp2(-u);
+  else if constexpr (KERNEL == K_ABSEXP) return kexp2(-u);
+  else return __builtin_amdgcn_rsqf(__builtin_fabsf(u));
+}
+
+// Scheduling pattern of one region: NM times { one MFMA, then its share of NTR transcendentals } (the shares differ by at
+// most one; the builtin wants literal constants, hence the recursion)
+template <int I, int NM, int NTR>
+__device__ __forceinline__ void mfma_sched_pattern() {
+  if constexpr (I < NM) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int share = (NTR * (I + 1)) / NM - (NTR * I) / NM;
+    if constexpr (share > 0) __builtin_amdgcn_sched_group_barrier(0x400, share, 0);
+    mfma_sched_pattern<I + 1, NM, NTR>();
+  }
+}
+
 // row of the 32x32 accumulator held in register `reg` by lane half `h`
 __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -95,11 +122,13 @@ __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
 
 template <int KERNEL, int KS, int NT, int TW>
 __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
+  constexpr int WPB = WAVES_PER_BLOCK;
   constexpr int KD = 16 * KS;
   constexpr int YS = mfma_y_stride(KS);
   constexpr int IMG = mfma_image_bytes(KS, NT);
-  constexpr int PIECES = IMG / (16 * BLOCK_THREADS);
-  static_assert(IMG % (16 * BLOCK_THREADS) == 0, "image is a whole number of pieces per thread");
+  constexpr int NPIECES = IMG / 1024;               // 1 KiB pieces of an image, dealt to the waves round robin
+  constexpr int PIECES = (NPIECES + WPB - 1) / WPB;
+  static_assert(IMG % 1024 == 0, "image is a whole number of LDS-DMA pieces");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][IMG];
 
   int tb, seg;
@@ -109,7 +138,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
   const int r = lane & 31;
   const int h = lane >> 5;
   // a wave owns TW target tiles of 32; the source fragments it reads from LDS serve all of them
-  const int64_t i0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * (MFMA_TILE * TW);
+  const int64_t i0 = ((int64_t)tb * WPB + wave) * (MFMA_TILE * TW);
 
   // B operand of the distance product: this lane's targets, 8 consecutive k per k-step
   bf16x8 xb[TW][KS];
@@ -166,10 +195,11 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
     const unsigned char* src = a.img + t * IMG;
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
-      const int piece = (p * WAVES_PER_BLOCK + wave) * 1024;  // wave-uniform LDS offset
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + piece + lane * 16),
-          (__attribute__((address_space(3))) void*)(&lds[buf][piece]), 16, 0, 0);
+      const int piece = (p * WPB + wave) * 1024;  // wave-uniform LDS offset
+      if (NPIECES % WPB == 0 || piece < IMG)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + piece + lane * 16),
+            (__attribute__((address_space(3))) void*)(&lds[buf][piece]), 16, 0, 0);
     }
   };
   if (t_begin < t_end) stage_tile(t_begin, 0);
@@ -270,8 +300,23 @@ constexpr int MFMA_PIPE_MAX_NT = 2;
 template <int KERNEL>
 __host__ __device__ constexpr int MFMA_TRANS_PER_PAIR() { return KERNEL == K_ABSEXP ? 2 : 1; }
 
-template <int KERNEL, int KS, int NT>
+// VAR (compile time; the "mfma_variant" option picks the instantiation):
+//   bit 0  DEN_MFMA  the denominators sum_j P[j][i] leave the VALU: one more accumulator tile SHARED by the wave's two
+//                    target tiles, fed by P x (a constant B operand with ones in column w for target tile w) -- 2 MFMAs
+//                    per tile pair instead of 16 v_add_f32 (the VALU, not the matrix pipe, is the busy unit here); the
+//                    sums are then over the bf16-rounded kernel values, the very numbers the numerators use
+//   bit 2  ROTATE    the loop is rotated by one transcendental stage: the FIRST stage of target tile 0's kernel
+//                    values of tile t + 1 (exp(-r): the square roots, in place in the distance registers) runs under the
+//                    P.V MFMAs of target tile 1 of tile t, and within a step the two stages of a tile's values always
+//                    sit in different scheduling regions (no transcendental waits for the one it depends on):
+//                      A: distances of t + 1 (2 KS MFMAs) | stage 2 of target tile 0, stage 1 of target tile 1
+//                      B: P.V of target tile 0            | stage 2 of target tile 1
+//                      C: P.V of target tile 1            | stage 1 of target tile 0 of tile t + 1
+template <int KERNEL, int KS, int NT, int VAR = 0>
 __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs a) {
+  constexpr bool DEN_MFMA = (VAR & 1) != 0;
+  constexpr bool ROTATE = (VAR & 4) != 0;
+  static_assert((VAR & 2) == 0, "bit 1 was the deferred-P.V arm: measured 5 % slower and removed (LAB_NOTES.md)");
   constexpr int TW = 2;
   constexpr int KD = 16 * KS;
   constexpr int YS = mfma_y_stride(KS);
@@ -315,7 +360,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
   }
 
   f32x16 o[TW][NT];
+  f32x16 oden;  // DEN_MFMA: column w holds the denominators of target tile w
   float den[TW];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) oden[q] = 0.f;
 #pragma unroll
   for (int w = 0; w < TW; ++w) {
     den[w] = 0.f;
@@ -324,6 +372,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
 #pragma unroll
       for (int q = 0; q < 16; ++q) o[w][nt][q] = 0.f;
   }
+  // B operand of the denominator product for target tile w: B[k][col] = 1 for col == w, all 16 k of a step
+  bf16x8 ones[TW];
+#pragma unroll
+  for (int w = 0; w < TW; ++w)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[w][j] = (__bf16)(r == w ? 1.f : 0.f);
 
   const int64_t t_begin = (int64_t)seg * a.seg_tiles;
   int64_t t_end = t_begin + a.seg_tiles;
@@ -368,7 +422,83 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
   f32x16 s_a[TW], s_b[TW];
   if (t_begin < t_end) distances(&lds[0][0], s_a);
 
+  // the P.V (and denominator) MFMAs of target tile w
+  auto pv = [&](int w, const bf16x8 (&pa)[2], const bf16x8 (&vb)[2][NT]) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[w][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2], vb[s2][nt], o[w][nt], 0, 0, 0);
+      if constexpr (DEN_MFMA) oden = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2], ones[w], oden, 0, 0, 0);
+    }
+  };
+  constexpr int PV_MFMAS = 2 * NT + (DEN_MFMA ? 2 : 0);
+  constexpr int TRANS = MFMA_TRANS_PER_PAIR<KERNEL>() * 16;  // quarter-rate instructions per target tile
+
   int buf = 0;  // image of tile t
+  // ROTATE: s_cur[0] arrives with stage 1 applied
+  auto step_rot = [&](int64_t t, f32x16 (&s_cur)[TW], f32x16 (&s_next)[TW]) {
+    const int buf1 = buf == 2 ? 0 : buf + 1;
+    const int buf2 = buf1 == 2 ? 0 : buf1 + 1;
+    if (t + 2 < t_end) stage_tile(t + 2, buf2);
+    const unsigned char* lv = &lds[buf][MFMA_TILE * YS];
+    bf16x8 vb[2][NT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const unsigned char* row = lv + (nt * 32 + r) * MFMA_V_STRIDE;
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 4 * h) * 2);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(row + (16 * s2 + 8 + 4 * h) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vb[s2][nt][j] = v0[j];
+          vb[s2][nt][4 + j] = v1[j];
+        }
+      }
+    const int64_t j0 = t * MFMA_TILE;
+    bool check = false;
+    if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
+    constexpr int T2 = 16;                                   // stage-2 transcendentals per target tile
+    constexpr int T1 = KERNEL == K_ABSEXP ? 16 : 0;          // stage-1 transcendentals per target tile
+    auto values = [&](int w, bf16x8 (&pa)[2]) {             // stage 2 + denominators + bf16 fragments
+      float p[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float k = mfma_kval_stage2<KERNEL>(s_cur[w][q]);
+        if constexpr (KERNEL == K_INVDIST) {
+          if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
+        }
+        p[q] = k;
+        if constexpr (!DEN_MFMA) den[w] += k;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pa[s2][j] = (__bf16)p[8 * s2 + j];
+    };
+    bf16x8 pa0[2], pa1[2];
+    // ---- region A
+    distances(&lds[buf1][0], s_next);
+    values(0, pa0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s_cur[1][q] = mfma_kval_stage1<KERNEL>(s_cur[1][q]);
+    mfma_sched_pattern<0, 2 * KS, T2 + T1>();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- region B
+    pv(0, pa0, vb);
+    values(1, pa1);
+    mfma_sched_pattern<0, PV_MFMAS, T2>();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- region C
+    pv(1, pa1, vb);
+    if constexpr (T1 > 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s_next[0][q] = mfma_kval_stage1<KERNEL>(s_next[0][q]);
+      mfma_sched_pattern<0, PV_MFMAS, T1>();
+    }
+    buf = buf1;
+    __syncthreads();
+  };
   auto step = [&](int64_t t, f32x16 (&s_cur)[TW], f32x16 (&s_next)[TW]) {
     const int buf1 = buf == 2 ? 0 : buf + 1;   // tile t + 1 (landed: waited for at the end of iteration t - 1)
     const int buf2 = buf1 == 2 ? 0 : buf1 + 1; // tile t + 2 (free: last read in iteration t - 1)
@@ -393,9 +523,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
     bool check = false;
     if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
 
-    // Three scheduling regions per source tile, each pairing MFMAs with independent VALU work of
-    // the same wave (an MFMA that cannot enter the matrix pipe yet blocks the wave's following
-    // instructions, so the MFMAs are spread between the transcendentals, not bunched):
+    // Scheduling regions per source tile, each pairing MFMAs with independent VALU work of the same wave (an MFMA that
+    // cannot enter the matrix pipe yet blocks the wave's following instructions, so the MFMAs are spread between the
+    // transcendentals, not bunched):
     //   A: distances of tile t + 1 (2 KS MFMAs)      | kernel values of target tile 0
     //   B: P.V of target tile 0 (2 NT MFMAs)         | kernel values of target tile 1
     //   C: P.V of target tile 1 (2 NT MFMAs), barrier
@@ -413,59 +543,69 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
           if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
         }
         p[q] = k;
-        den[w] += k;
+        if constexpr (!DEN_MFMA) den[w] += k;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pa[w][s2][j] = (__bf16)p[8 * s2 + j];
-      if (w > 0) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            o[w - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[w - 1][s2], vb[s2][nt], o[w - 1][nt], 0, 0, 0);
-      }
+      if (w > 0) pv(w - 1, pa[w - 1], vb);
       // one MFMA, then enough transcendentals to cover its 32 cycles on the matrix pipe
       if (w == 0) {
+        constexpr int NM = 2 * KS;
 #pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) {
+        for (int i = 0; i < NM; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x400, MFMA_TRANS_PER_PAIR<KERNEL>() * 16 / (2 * KS) > 0 ? MFMA_TRANS_PER_PAIR<KERNEL>() * 16 / (2 * KS) : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, TRANS / NM > 0 ? TRANS / NM : 1, 0);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 2 * NT; ++i) {
+        for (int i = 0; i < PV_MFMAS; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x400, MFMA_TRANS_PER_PAIR<KERNEL>() * 16 / (2 * NT), 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, TRANS / PV_MFMAS, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        o[TW - 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TW - 1][s2], vb[s2][nt], o[TW - 1][nt], 0, 0, 0);
+    pv(TW - 1, pa[TW - 1], vb);
     buf = buf1;
     __syncthreads();  // tile t + 2 has landed (vmcnt(0)), nobody reads image t any more
   };
   int64_t t = t_begin;
-  for (; t + 1 < t_end; t += 2) {
-    step(t, s_a, s_b);
-    step(t + 1, s_b, s_a);
+  if constexpr (ROTATE) {
+    if (t_begin < t_end) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s_a[0][q] = mfma_kval_stage1<KERNEL>(s_a[0][q]);
+    }
+    for (; t + 1 < t_end; t += 2) {
+      step_rot(t, s_a, s_b);
+      step_rot(t + 1, s_b, s_a);
+    }
+    if (t < t_end) step_rot(t, s_a, s_b);
+  } else {
+    for (; t + 1 < t_end; t += 2) {
+      step(t, s_a, s_b);
+      step(t + 1, s_b, s_a);
+    }
+    if (t < t_end) step(t, s_a, s_b);
   }
-  if (t < t_end) step(t, s_a, s_b);
 
 #pragma unroll
   for (int w = 0; w < TW; ++w) {
-    const float dsum = den[w] + __shfl_xor(den[w], 32);
     float* part = a.part + ((int64_t)seg * a.n_pad + i0 + w * MFMA_TILE) * (NT * 32);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) part[(int64_t)acc_row(q, h) * (NT * 32) + nt * 32 + r] = o[w][nt][q];
-    if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = dsum;
+    if constexpr (DEN_MFMA) {
+      if (r == w) {  // column w of the shared tile: rows = targets of tile w
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + acc_row(q, h)] = oden[q];
+      }
+    } else {
+      const float dsum = den[w] + __shfl_xor(den[w], 32);
+      if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = dsum;
+    }
   }
 }
 

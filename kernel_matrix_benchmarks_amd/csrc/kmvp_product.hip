@@ -1624,6 +1624,9 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   // 2 with the software-pipelined kernel
   const int TW = c->opt_T == 1 ? 1 : 2;
   const bool pipelined = TW == 2 && c->opt_T != 2 && KS <= MFMA_PIPE_MAX_KS && NT <= MFMA_PIPE_MAX_NT;
+  // variant of the pipelined kernel (kmvp_mfma.hpp VAR): exp(-r) by default rotated with the denominators on the matrix
+  // pipe (two transcendentals per pair: profiles/r03_c3_variants.txt); the single-transcendental kernels gain nothing
+  const int variant = c->opt_mfma_variant >= 0 ? c->opt_mfma_variant : (kernel == K_ABSEXP ? 5 : 0);
   const int64_t tile = (int64_t)MFMA_TILE * TW * WAVES_PER_BLOCK;
   const int64_t n_pad = round_up(N, tile);
   const int64_t tile_blocks = n_pad / tile;
@@ -1679,9 +1682,9 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   HIP_TRY(c, mark(c, 0));
   hipError_t le;
   switch (kernel) {
-    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
-    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
-    default: le = launch_mfma_invdist(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_ABSEXP: le = launch_mfma_absexp(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
+    default: le = launch_mfma_invdist(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
   }
   HIP_TRY(c, le);
   HIP_TRY(c, mark(c, 1));
