@@ -301,10 +301,10 @@ template <int KERNEL>
 __host__ __device__ constexpr int MFMA_TRANS_PER_PAIR() { return KERNEL == K_ABSEXP ? 2 : 1; }
 
 // VAR (compile time; the "mfma_variant" option picks the instantiation):
-//   bit 0  DEN_MFMA  the denominators sum_j P[j][i] leave the VALU: one more accumulator tile SHARED by the wave's two
-//                    target tiles, fed by P x (a constant B operand with ones in column w for target tile w) -- 2 MFMAs
-//                    per tile pair instead of 16 v_add_f32 (the VALU, not the matrix pipe, is the busy unit here); the
-//                    sums are then over the bf16-rounded kernel values, the very numbers the numerators use
+//   bit 0  DEN_MFMA  the denominators sum_j P[j][i] leave the VALU: one more accumulator tile per target tile, fed by
+//                    P x (a constant B operand with ones in column 0) -- 2 MFMAs per tile pair instead of 16 v_add_f32
+//                    (the VALU, not the matrix pipe, is the busy unit here); the sums are then over the bf16-rounded
+//                    kernel values, the very numbers the numerators use
 //   bit 2  ROTATE    the loop is rotated by one transcendental stage: the FIRST stage of target tile 0's kernel
 //                    values of tile t + 1 (exp(-r): the square roots, in place in the distance registers) runs under the
 //                    P.V MFMAs of target tile 1 of tile t, and within a step the two stages of a tile's values always
@@ -360,24 +360,23 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
   }
 
   f32x16 o[TW][NT];
-  f32x16 oden;  // DEN_MFMA: column w holds the denominators of target tile w
+  f32x16 oden[TW];  // DEN_MFMA: column 0 holds the denominators of target tile w (a tile of its own per target tile: a
+                    // shared one would let a NaN row of one tile -- NaN x 0 -- into the other tile's sums)
   float den[TW];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) oden[q] = 0.f;
 #pragma unroll
   for (int w = 0; w < TW; ++w) {
     den[w] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) oden[w][q] = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) o[w][nt][q] = 0.f;
   }
-  // B operand of the denominator product for target tile w: B[k][col] = 1 for col == w, all 16 k of a step
-  bf16x8 ones[TW];
+  // B operand of the denominator product: B[k][col] = 1 for col == 0, all 16 k of a step
+  bf16x8 ones;
 #pragma unroll
-  for (int w = 0; w < TW; ++w)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[w][j] = (__bf16)(r == w ? 1.f : 0.f);
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)(r == 0 ? 1.f : 0.f);
 
   const int64_t t_begin = (int64_t)seg * a.seg_tiles;
   int64_t t_end = t_begin + a.seg_tiles;
@@ -428,7 +427,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[w][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2], vb[s2][nt], o[w][nt], 0, 0, 0);
-      if constexpr (DEN_MFMA) oden = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2], ones[w], oden, 0, 0, 0);
+      if constexpr (DEN_MFMA) oden[w] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[s2], ones, oden[w], 0, 0, 0);
     }
   };
   constexpr int PV_MFMAS = 2 * NT + (DEN_MFMA ? 2 : 0);
@@ -598,9 +597,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
 #pragma unroll
       for (int q = 0; q < 16; ++q) part[(int64_t)acc_row(q, h) * (NT * 32) + nt * 32 + r] = o[w][nt][q];
     if constexpr (DEN_MFMA) {
-      if (r == w) {  // column w of the shared tile: rows = targets of tile w
+      if (r == 0) {  // column 0 of the tile: rows = targets
 #pragma unroll
-        for (int q = 0; q < 16; ++q) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + acc_row(q, h)] = oden[q];
+        for (int q = 0; q < 16; ++q) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + acc_row(q, h)] = oden[w][q];
       }
     } else {
       const float dsum = den[w] + __shfl_xor(den[w], 32);

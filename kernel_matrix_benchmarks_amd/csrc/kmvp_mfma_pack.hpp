@@ -15,14 +15,15 @@ __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16&
   lo = (__bf16)(r1 - (float)mid);
 }
 
-// targets (N,D) f32 -> augmented bf16 rows [n_pad][KD]; pad targets are all-zero rows
+// targets (N,D) f32 -> augmented bf16 rows [n_pad][KD]; pad targets are the origin (S = |y|^2: finite against live
+// sources, +inf against pad sources -- an all-zero row would make that inf x 0 = NaN)
 __global__ void pack_mfma_targets_kernel(const float* __restrict__ x, __bf16* __restrict__ xa,
                                          int64_t n, int64_t n_pad, int D, int KD, float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
   __bf16* row = xa + i * KD;
   if (i >= n) {
-    for (int k = 0; k < KD; ++k) row[k] = (__bf16)0.f;
+    for (int k = 0; k < KD; ++k) row[k] = (__bf16)((k >= D && k < D + 3) ? 1.f : 0.f);
     return;
   }
   float sq = 0.f;

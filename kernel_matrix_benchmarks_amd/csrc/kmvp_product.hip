@@ -1624,9 +1624,11 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   // 2 with the software-pipelined kernel
   const int TW = c->opt_T == 1 ? 1 : 2;
   const bool pipelined = TW == 2 && c->opt_T != 2 && KS <= MFMA_PIPE_MAX_KS && NT <= MFMA_PIPE_MAX_NT;
-  // variant of the pipelined kernel (kmvp_mfma.hpp VAR): exp(-r) by default rotated with the denominators on the matrix
-  // pipe (two transcendentals per pair: profiles/r03_c3_variants.txt); the single-transcendental kernels gain nothing
-  const int variant = c->opt_mfma_variant >= 0 ? c->opt_mfma_variant : (kernel == K_ABSEXP ? 5 : 0);
+  // variant of the pipelined kernel (kmvp_mfma.hpp VAR): exp(-r) (two transcendentals per pair) by default with the loop
+  // rotated by one transcendental stage; the denominators stay on the VALU -- on the matrix pipe they save 2 % of the
+  // cycles and nothing of the time under the power limit (profiles/r03_c3_variants.txt); the single-transcendental kernels
+  // gain nothing from either
+  const int variant = c->opt_mfma_variant >= 0 ? c->opt_mfma_variant : (kernel == K_ABSEXP ? 4 : 0);
   const int64_t tile = (int64_t)MFMA_TILE * TW * WAVES_PER_BLOCK;
   const int64_t n_pad = round_up(N, tile);
   const int64_t tile_blocks = n_pad / tile;

@@ -1064,6 +1064,43 @@ def test_config3_attention_65536_row_subset():
         assert a.min() >= b.min() - 0.05 and a.max() <= b.max() + 0.05  # convex combinations
 
 
+def test_config3_attention_65536_with_contrast():
+    """The C3 shape (N = M = 65536, D = 64, E = 64, exp(-r), row-normalised, bf16) on a cloud that DISCRIMINATES: in the
+    bench's uniform cloud / sqrt(D) all distances are 0.41 +- 0.03, the weights differ by +-3 % and every row is close to
+    the column mean of b -- a kernel whose weights were 10 % off would pass at 1e-2.  Here 64
+    clusters of 1024 points (cluster radius ~0.25, centres up to ~4 apart) give distances from 0 to ~4: within a row the
+    weights span e^0 ... e^-4 and the answer is dominated by the target's own cluster, so the value rows of that cluster
+    -- not the global mean -- must come out.  128 rows against the float64 C oracle at the bf16 tolerance; every variant
+    of the pipelined kernel and the plain kernel."""
+    n, D, E = 65536, 64, 64
+    rs = np.random.RandomState(n + D + 1)
+    centres = rs.randn(64, D) * (2.0 / np.sqrt(D))          # |c - c'| ~ 2.8
+    y = np.repeat(centres, n // 64, axis=0) + rs.randn(n, D) * (0.25 / np.sqrt(D))
+    b = rs.randn(n, E) + np.repeat(rs.randn(64, E) * 3.0, n // 64, axis=0)  # value rows differ by cluster
+    perm = rs.permutation(n)
+    y, b = y[perm], b[perm]
+    rows = np.random.RandomState(1).choice(n, size=128, replace=False)
+    want = c_oracle.product(kernel="absolute-exponential", source_points=y, source_signal=b, normalize_rows=True, rows=rows)
+    r = np.sqrt(((y[rows[:8], None, :] - y[None, ::64, :]) ** 2).sum(-1))
+    assert r.min() < 0.6 and r.max() > 3.0, (r.min(), r.max())  # the weights of a row span more than e^-2.4
+    col_mean = b.mean(axis=0)
+    assert rel_err(np.tile(col_mean, (128, 1)), want) > 0.2  # "every row = the mean" is far outside the tolerance here
+    seen = []
+    for opts in (dict(), dict(mfma_variant=0), dict(mfma_variant=1), dict(mfma_variant=5), dict(targets_per_lane=2)):
+        algo = MI355XProduct(kernel="absolute-exponential", dimension=D, normalize_rows=True, precision="bfloat16")
+        try:
+            algo.prepare_data(source_points=y, target_points=y, same_points=True)
+            algo.set_query_arguments(**opts)
+            algo.prepare_query(source_signal=b)
+            algo.query()
+            a = algo.get_result()
+            seen.append(algo.device_kernel)
+        finally:
+            algo.done()
+        assert rel_err(a[rows], want) <= TOL_BF16, (opts, rel_err(a[rows], want))
+    assert seen[0] == "mfma_pipe_kernel" and seen[-1] == "mfma_kernel", seen
+
+
 def test_every_tuning_variant_gives_the_same_answer(expected):
     case = next(c for c in CASES if c["name"] == "gaussian-N257-M193-D3-E1")
     y, x, b = golden_cases.make_inputs(case)
