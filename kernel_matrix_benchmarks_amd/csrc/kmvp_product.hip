@@ -349,6 +349,20 @@ int choose_segments(const kmvp_ctx* c, int64_t tile_blocks, int64_t m_pad, int N
   return (int)seg;
 }
 
+// Segments are whole numbers of `units` (stages, tiles): `seg` requested segments become ceil(units / ceil(units / seg)),
+// which may be one or two fewer -- and no longer a multiple of 8.  block_to_work() streams one segment per XCD at a time only
+// when the count IS a multiple of 8 (measured, cfast_kernel at 2e5 points: 23 segments 5.65 ms, 16: 5.05, 32: 4.94), so the
+// nearest multiple of 8 that survives the rounding is taken (the request itself below 8).
+int settle_segments(int64_t units, int seg) {
+  auto settled = [&](int64_t cand) { return (units + (units + cand - 1) / cand - 1) / ((units + cand - 1) / cand); };
+  if (seg >= 8 && units >= 8)
+    for (int step = 0; step <= 64; step += 8)
+      for (int64_t cand : {(int64_t)seg + step, (int64_t)seg - step})
+        if (cand >= 8 && cand <= units && cand % 8 == 0 && settled(cand) == cand) return (int)cand;
+  seg = (int)std::max<int64_t>(1, std::min<int64_t>(seg, std::max<int64_t>(units, 1)));
+  return (int)settled(seg);
+}
+
 // The whole product: everything query() times.  `sig` as in kmvp_lowd.hpp.
 template <typename real>
 int run_product_t(kmvp_ctx* c, int kernel, int sig) {
@@ -592,8 +606,8 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   int rc;
 
   int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, SB, small ? 1 : 4, small);
+  segments = settle_segments(m_stages, segments);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
-  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
 
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
                          c->packed_layout != LAYOUT_FAST || c->packed_T != TT;
@@ -681,8 +695,8 @@ int run_product_fastmm(kmvp_ctx* c, int kernel, int sig, bool dot = false) {
   // (the kernel's time does not depend on the segment count between 8 and 48 at 1e5 points, the fp64 partial sums --
   // segments x columns x N x 8 bytes -- and their reduction do: about 4096 workgroups instead of 16384)
   int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small, 2 << 20, 4096);
+  segments = settle_segments(m_stages, segments);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
-  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
   if (tile_blocks * segments > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
 
   const int layout_T = TT + 16 * MODE;
@@ -823,9 +837,13 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   if (c->m_total > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "more than 2^31 sources");
   int rc;
 
-  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, CF_STAGE_BYTES, small ? 1 : 4, small);
+  // No L2-residency pull here (l2_seg_bytes = infinity): cfast_kernel runs as fast on 8 segments as on 40 - 48 at 1e6 and at
+  // 1e7 x 1.25e6 points (tools/c4_segments.py: 117.2 / 116.5 ms, 1442 / 1447 ms), and every segment costs N x 16 bytes of
+  // partial sums written and read back -- config 4's shard: 48 -> 8 segments, 7.7 -> 1.3 GB.  Few targets still get more
+  // segments for parallelism (2e5 points: 16).
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, CF_STAGE_BYTES, small ? 1 : 4, small, (int64_t)1 << 40, 24576);
+  segments = settle_segments(m_stages, segments);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
-  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
 
   if ((rc = morton_order(c, m_alloc))) return rc;
   const bool pts_stale = c->packed_points_ver != c->points_ver || c->packed_kernel != kernel ||
@@ -905,8 +923,8 @@ int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
   int rc;
 
   int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small, 2 << 20, 4096);
+  segments = settle_segments(m_stages, segments);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
-  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
   if (tile_blocks * segments > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "launch grid too large");
 
   if ((rc = morton_order(c, m_alloc))) return rc;
@@ -1254,8 +1272,8 @@ int run_product_cell(kmvp_ctx* c, int sig) {
 
   int segments = choose_segments(c, std::max<int64_t>(1, tile_blocks), m_stages, NE, n_slots, CELL_STAGE_BYTES,
                                  small ? 1 : 4, small);
+  segments = settle_segments(m_stages, segments);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
-  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
   // the launch over the leftover tiles: its own, finer split of the sources and its own region of partial sums
   int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, NE, n_slots, CELL_STAGE_BYTES, 1, small, 2 << 20, 1536) : 0;
   const int64_t rest_seg_stages = rest_blocks > 0 ? (m_stages + rest_segments - 1) / rest_segments : 1;
@@ -1377,8 +1395,8 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   // pass over the targets, so the fewest that keep the chip full are taken (HBM-side traffic 0.44 -> 0.25 GB).
   int segments = choose_segments(c, std::max<int64_t>(1, tile_blocks), m_stages, 1, n_slots, CMM_STAGE_BYTES,
                                  small ? 1 : 2, small, 3 << 20, 7168);
+  segments = settle_segments(m_stages, segments);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
-  segments = (int)((m_stages + seg_stages - 1) / seg_stages);
   // the launch over the leftover tiles (two per wavefront, few workgroups) gets its own, finer split of the sources --
   // it is latency-bound per workgroup, so it needs many of them -- and its own region of partial sums
   int rest_segments = rest_blocks > 0 ? choose_segments(c, rest_blocks, m_stages, 1, n_slots, CMM_STAGE_BYTES, 1, small, 3 << 20, 1536) : 0;
