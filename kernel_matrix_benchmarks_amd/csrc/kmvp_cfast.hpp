@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfast_kernel(const CfastArgs a)
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int64_t i = (tile0 + tt) * 32 + r;
-    const cf32x4 v = *reinterpret_cast<const cf32x4*>(a.xraw + i * 4);
+    // (non-temporal: a workgroup's targets and partial sums are touched once, the 2 MiB source segment its XCD streams is
+    // re-read by every workgroup -- they must not push it out of the 4 MiB L2: profiles/r03_c4shard_segments_fetch.txt)
+    const cf32x4 v = __builtin_nontemporal_load(reinterpret_cast<const cf32x4*>(a.xraw + i * 4));
 #pragma unroll
     for (int d = 0; d < 4; ++d) x[tt][d] = v[d];
     if constexpr (KERNEL == K_INVDIST) {
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfast_kernel(const CfastArgs a)
     for (int e = 0; e < NE; ++e) {
       double v = accd[tt][e] + (double)acc[tt][e];
       v += __shfl_xor(v, 32);
-      if (h == 0) a.part[((int64_t)seg * NE + e) * a.n_pad + (tile0 + tt) * 32 + r] = v;
+      if (h == 0) __builtin_nontemporal_store(v, &a.part[((int64_t)seg * NE + e) * a.n_pad + (tile0 + tt) * 32 + r]);
     }
 }
 

@@ -841,7 +841,7 @@ int run_product_cfast(kmvp_ctx* c, int kernel, int sig) {
   // 1e7 x 1.25e6 points (tools/c4_segments.py: 117.2 / 116.5 ms, 1442 / 1447 ms), and every segment costs N x 16 bytes of
   // partial sums written and read back -- config 4's shard: 48 -> 8 segments, 7.7 -> 1.3 GB.  Few targets still get more
   // segments for parallelism (2e5 points: 16).
-  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, CF_STAGE_BYTES, small ? 1 : 4, small, (int64_t)1 << 40, 24576);
+  int segments = choose_segments(c, tile_blocks, m_stages, NE, n_pad, CF_STAGE_BYTES, small ? 1 : 4, small, 2 << 20, 24576);
   segments = settle_segments(m_stages, segments);
   const int64_t seg_stages = (m_stages + segments - 1) / segments;
 
