@@ -2,7 +2,16 @@
 // squared distances (kmvp_cfast.hpp: expansion around per-group centres of Morton-sorted sources, exact recomputation of
 // the closest pairs, RELATIVE accuracy in s) feeding fastmm_kernel's second product (kmvp_fastmm.hpp: the tile of kernel
 // values split into two f16 pieces and multiplied with the pre-packed signal operand by f16 MFMAs, up to 32 columns per
-// pass).  float32, D <= 4.  The inverse-distance kernel is excluded: its values are unbounded, f16 pieces overflow.
+// pass).  float32, D <= 4.
+//
+// 1/r (KERNEL = K_INVDIST, always with the online shift; needs targets == sources, as cfast_kernel's zero rule does): the
+// values are unbounded, so the per-target shift kop = floor(log2 r_min) of "The shift" (kmvp_fastmm.hpp) is what makes the
+// f16 pieces possible at all: T = 2^(15 + kop) / r <= 2^15.5.  It costs nothing per pair: s is linear in the TARGET operand
+// (every term of |x''|^2 + |y'|^2 - 2 x''.y' carries exactly one target-side factor), the operand is rebuilt per (target
+// tile, group) anyway, so it is built times c = 4^-(15 + kop) -- a power of two, exact in the bf16 pieces -- and
+// T = rsq(c s) comes out of the one transcendental.  The pair that carries the target's own ORIGINAL index is dropped in
+// the exact branch (s = +inf: bruteforce.py:13-14), a coincident other pair gives T = inf -> NaN sums for that target,
+// as the reference's inf / nan row.
 //
 //   per (target tile, group of 128 sources): target operand relative to the group's centre (as cfast_kernel)
 //   per row tile of 32 sources:  S = Y~ X~^T (2 bf16 MFMAs)  ->  [near pairs: exact s]  ->  T = 2^15 k(s)
@@ -21,7 +30,8 @@ namespace kmvp {
 
 constexpr int CFM_OFF_SIG = CF_HDR + CF_GROUP * CF_ROW_BYTES;
 __host__ __device__ constexpr int cfm_off_raw(int MODE) { return CFM_OFF_SIG + (CF_GROUP / 32) * fmm_sig_bytes(MODE); }
-__host__ __device__ constexpr int cfm_group_bytes(int MODE) { return cfm_off_raw(MODE) + CF_GROUP * 16; }
+__host__ __device__ constexpr int cfm_off_idx(int MODE) { return cfm_off_raw(MODE) + CF_GROUP * 16; }  // int32 GLOBAL original source index, -1: pad
+__host__ __device__ constexpr int cfm_group_bytes(int MODE) { return cfm_off_idx(MODE) + CF_GROUP * 4; }
 __host__ __device__ constexpr int cfm_stage_bytes(int MODE) { return (cfm_group_bytes(MODE) + 4095) / 4096 * 4096; }
 
 struct CfastmmArgs {
@@ -37,13 +47,15 @@ struct CfastmmArgs {
   int chunk_stages;
   int NE;
   float scale;               // the kernel's constant, applied AFTER a difference is formed
+  int64_t m_total;           // 1/r: the zero rule works on global indices (bruteforce.py:13-14)
 };
 
 // T = 2^sh k(s), sh = FMM_SHIFT [+ the target's online shift]
 template <int KERNEL>
 __device__ __forceinline__ float cfm_tval(float s, float sh) {
   if constexpr (KERNEL == K_GAUSSIAN) return kexp2(sh - s);
-  else return kexp2(sh - __builtin_amdgcn_sqrtf(__builtin_fabsf(s)));
+  else if constexpr (KERNEL == K_ABSEXP) return kexp2(sh - __builtin_amdgcn_sqrtf(__builtin_fabsf(s)));
+  else return __builtin_amdgcn_rsqf(__builtin_fabsf(s));  // 1/r: s arrives scaled by 4^-sh (see the header)
 }
 
 // ONLINE = 1: per-target running shift kop = floor(smallest exponent seen so far), T = 2^(15 + kop) k -- see "The shift" in
@@ -51,7 +63,7 @@ __device__ __forceinline__ float cfm_tval(float s, float sh) {
 // pays the running minimum of the tile (8 v_min3 + one v_permlane32_swap) and a rare wave-uniform rescale branch.
 template <int KERNEL, int MODE, int TT, int ONLINE = 0>
 __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArgs a) {
-  static_assert(KERNEL == K_GAUSSIAN || KERNEL == K_ABSEXP, "bounded kernels only");
+  static_assert(KERNEL != K_INVDIST || ONLINE == 1, "1/r needs the per-target shift");
   constexpr int SB = cfm_stage_bytes(MODE);
   constexpr int PIECES = SB / (16 * BLOCK_THREADS);
   constexpr int NOUT = MODE ? 16 : 8;
@@ -67,11 +79,17 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
   const int64_t tile0 = ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
 
   float x[TT][4];
+  int jz[TT];      // 1/r: GLOBAL source index whose pair the target drops
+  float csc[TT];   // 1/r: c = 4^-(15 + kop), the scale of the target operand (and so of s)
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
-    const cf32x4 v = *reinterpret_cast<const cf32x4*>(a.xraw + ((tile0 + tt) * 32 + r) * 4);
+    const int64_t i = (tile0 + tt) * 32 + r;
+    const cf32x4 v = *reinterpret_cast<const cf32x4*>(a.xraw + i * 4);
 #pragma unroll
     for (int d = 0; d < 4; ++d) x[tt][d] = v[d];
+    const int64_t g = i % (a.m_total + 1);
+    jz[tt] = (KERNEL == K_INVDIST && g < a.m_total) ? (int)g : -2;
+    csc[tt] = KERNEL == K_INVDIST ? 9.313225746154785e-10f : 1.f;  // 4^-15
   }
 
   f32x16 acc[TT];
@@ -130,25 +148,31 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
 
     // target operands relative to the group's centre (kmvp_cfast.hpp): this lane half holds dims h and h + 2
     bf16x8 xb[TT][2];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
+    // (c: 1, or for 1/r the target's power-of-two scale -- every piece is scaled exactly, and so is s)
+    auto build_xb = [&](int tt, float c) -> float {
       const float x0 = (x[tt][0] - cen[0]) * a.scale, x1 = (x[tt][1] - cen[1]) * a.scale;
       const float x2 = (x[tt][2] - cen[2]) * a.scale, x3 = (x[tt][3] - cen[3]) * a.scale;
       const float sq = fmaf(x3, x3, fmaf(x2, x2, fmaf(x1, x1, x0 * x0)));
-      const float xa = h ? x1 : x0, xc = h ? x3 : x2;
+      const float xa = (h ? x1 : x0) * c, xc = (h ? x3 : x2) * c;
       float ah, am, al, ch, cm, cl, sh, sm, sl;
       cf_split(xa, ah, am, al);
       cf_split(xc, ch, cm, cl);
-      cf_split(sq, sh, sm, sl);
+      cf_split(sq * c, sh, sm, sl);
       bf16x8 b0, b1;
       b0[0] = (__bf16)ah; b0[1] = (__bf16)am; b0[2] = (__bf16)ah; b0[3] = (__bf16)al;
-      b0[4] = (__bf16)am; b0[5] = (__bf16)ah; b0[6] = (__bf16)1.f; b0[7] = (__bf16)(h ? sh : 1.f);
+      b0[4] = (__bf16)am; b0[5] = (__bf16)ah; b0[6] = (__bf16)c; b0[7] = (__bf16)(h ? sh : c);
       b1[0] = (__bf16)ch; b1[1] = (__bf16)cm; b1[2] = (__bf16)ch; b1[3] = (__bf16)cl;
       b1[4] = (__bf16)cm; b1[5] = (__bf16)ch; b1[6] = (__bf16)(h ? 0.f : sm); b1[7] = (__bf16)(h ? 0.f : sl);
       xb[tt][0] = b0;
       xb[tt][1] = b1;
+      return sq;
+    };
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const float sq = build_xb(tt, csc[tt]);
       near_mask |= (__ballot(!(sq > reach2 && sq <= 3.0e38f)) != 0ull ? 1u : 0u) << tt;
     }
+    const int* lidx = reinterpret_cast<const int*>(lg + cfm_off_idx(MODE));
 
 #pragma unroll 1
     for (int rt = 0; rt < CF_GROUP / 32; ++rt) {
@@ -180,33 +204,69 @@ __global__ void __launch_bounds__(BLOCK_THREADS) cfastmm_kernel(const CfastmmArg
           for (int q = 3; q < 15; q += 2) dmin = fminf(fminf(dmin, d[q]), d[q + 1]);
           dmin = fminf(dmin, d[15]);
         }
-        if (gate && __any(!(dmin > tau))) {
+        const float tau_c = tau * csc[tt];  // (d is c s)
+        if (gate && __any(!(dmin > tau_c))) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            if (!(d[q] > tau)) {
-              const cf32x4 yr = lraw[rt * 32 + acc_row(q, h)];
+            if (!(d[q] > tau_c)) {
+              const int row = rt * 32 + acc_row(q, h);
+              const cf32x4 yr = lraw[row];
               const float e0 = (x[tt][0] - yr[0]) * a.scale, e1 = (x[tt][1] - yr[1]) * a.scale;
               const float e2 = (x[tt][2] - yr[2]) * a.scale, e3 = (x[tt][3] - yr[3]) * a.scale;
-              d[q] = fmaf(e3, e3, fmaf(e2, e2, fmaf(e1, e1, e0 * e0)));
+              float sx = fmaf(e3, e3, fmaf(e2, e2, fmaf(e1, e1, e0 * e0))) * csc[tt];
+              if constexpr (KERNEL == K_INVDIST) {
+                if (lidx[row] == jz[tt]) sx = INFINITY;  // the target's own index: k = 0 (bruteforce.py:13-14)
+              }
+              d[q] = sx;
             }
+          }
+          if constexpr (ONLINE) {  // the minimum the shift follows must not see the dropped pair
+            dmin = fminf(fminf(d[0], d[1]), d[2]);
+#pragma unroll
+            for (int q = 3; q < 15; q += 2) dmin = fminf(fminf(dmin, d[q]), d[q + 1]);
+            dmin = fminf(dmin, d[15]);
           }
         }
         if constexpr (ONLINE) {
           // smallest exponent of the tile for this target (both lane halves): s for the Gaussian, r for exp(-r); the
           // exactly recomputed pairs are >= 0 and at most tau away from what dmin saw
           float m = fmm_min_halves(dmin);
-          if constexpr (KERNEL == K_ABSEXP) m = __builtin_amdgcn_sqrtf(fmaxf(m, 0.f));
-          else m = fmaxf(m, 0.f);
           const bool first = s == s_begin && rt == 0;
-          const bool need = (first || m < kop[tt] - 0.5f) && m < 3.0e38f;  // (hysteresis: T up to 2^15.5 is still an f16 number)
-          if (__any(need)) {  // rare
-            fold_one(tt);
-            if (need) {
-              const float kn = floorf(m);
-              const int di = (int)(kop[tt] - kn);  // >= 0 except at the first tile (nothing accumulated yet)
+          if constexpr (KERNEL == K_INVDIST) {
+            // m = c s_min; the tile's largest T is rsq(m): 2^15.5 at m = 2^-31.  New shift from the exponent of the
+            // UNSCALED s_min = m 4^(15 + kop) = f 2^e, f in [0.5, 1): kop = floor((e - 1) / 2) <= log2 r_min.
+            // m == 0 (a coincident pair that is not the target's own): nothing to scale to, T = inf, the row goes NaN.
+            const bool need = (first || m < 4.656612873077393e-10f) && m > 0.f && m < 3.0e38f;
+            if (__any(need)) {
+              fold_one(tt);
+              if (need) {
+                int e;
+                (void)frexpf(m, &e);
+                const int kn = ((e - 1) >> 1) + 15 + (int)kop[tt];  // floor((e_unscaled - 1) / 2), e_unscaled = e + 2 (15 + kop)
+                const int di = (int)kop[tt] - kn;
+                const float f = ldexpf(1.f, 2 * di);            // c_new / c_old = 4^(kop_old - kn)
 #pragma unroll
-              for (int q = 0; q < NOUT; ++q) accd[tt][q] = ldexp(accd[tt][q], -di);
-              kop[tt] = kn;
+                for (int q = 0; q < 16; ++q) d[q] *= f;
+#pragma unroll
+                for (int q = 0; q < NOUT; ++q) accd[tt][q] = ldexp(accd[tt][q], -di);
+                kop[tt] = (float)kn;
+                csc[tt] *= f;
+              }
+              (void)build_xb(tt, csc[tt]);  // the remaining row tiles of this group
+            }
+          } else {
+            if constexpr (KERNEL == K_ABSEXP) m = __builtin_amdgcn_sqrtf(fmaxf(m, 0.f));
+            else m = fmaxf(m, 0.f);
+            const bool need = (first || m < kop[tt] - 0.5f) && m < 3.0e38f;  // (hysteresis: T up to 2^15.5 is still an f16 number)
+            if (__any(need)) {  // rare
+              fold_one(tt);
+              if (need) {
+                const float kn = floorf(m);
+                const int di = (int)(kop[tt] - kn);  // >= 0 except at the first tile (nothing accumulated yet)
+#pragma unroll
+                for (int q = 0; q < NOUT; ++q) accd[tt][q] = ldexp(accd[tt][q], -di);
+                kop[tt] = kn;
+              }
             }
           }
         }

@@ -1,4 +1,4 @@
-// Instantiations of cfastmm_kernel (kmvp_cfastmm.hpp): kernel (Gaussian, exp(-r)), MODE = 0 (<= 16 columns) / 1 (<= 32),
+// Instantiations of cfastmm_kernel (kmvp_cfastmm.hpp): kernel (Gaussian, exp(-r), 1/r), MODE = 0 (<= 16 columns) / 1 (<= 32),
 // TT = target tiles of 32 per wave (1 or 2).
 #include "kmvp_internal.hpp"
 #include "kmvp_cfastmm.hpp"
@@ -26,6 +26,8 @@ hipError_t launch_cfastmm(int kernel, int mode, int TT, int online, const Cfastm
   if (kernel_name) *kernel_name = "cfastmm_kernel";  // (ONLINE = 1 shows in the dispatch note)
   if (kernel == K_GAUSSIAN) return launch_mode<K_GAUSSIAN>(mode, TT, online, args, grid, stream);
   if (kernel == K_ABSEXP) return launch_mode<K_ABSEXP>(mode, TT, online, args, grid, stream);
+  if (kernel == K_INVDIST)  // unbounded values: only with the per-target shift
+    return mode ? launch_tt<K_INVDIST, 1, 1>(TT, args, grid, stream) : launch_tt<K_INVDIST, 0, 1>(TT, args, grid, stream);
   return hipErrorInvalidValue;
 }
 

@@ -11,10 +11,11 @@ namespace kmvp {
 __global__ void __launch_bounds__(CF_GROUP) pack_cfastmm_points_kernel(const float* __restrict__ y,
                                                                       const int* __restrict__ perm,
                                                                       unsigned char* __restrict__ img, int64_t m, int D,
-                                                                      int MODE, float scale) {
+                                                                      int MODE, float scale, int64_t j_offset) {
   const int64_t group = blockIdx.x;
   unsigned char* g = img + group * (int64_t)cfm_stage_bytes(MODE);
-  (void)cfast_pack_group_points(y, perm, g, cfm_off_raw(MODE), group, m, D, scale);
+  const int src = cfast_pack_group_points(y, perm, g, cfm_off_raw(MODE), group, m, D, scale);
+  reinterpret_cast<int*>(g + cfm_off_idx(MODE))[threadIdx.x] = src < m ? (int)(j_offset + src) : -1;
 }
 
 // the signal operands of every row tile, in the sorted order of the sources: pack_fastmm_signal_kernel's layout

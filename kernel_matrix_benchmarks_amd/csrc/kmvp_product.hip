@@ -919,7 +919,7 @@ int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
   const int64_t m_alloc = m_stages * CF_GROUP;
   const int nb_max = std::min(NE, FMM_MAX_COLS);
   if (c->m_total > 0x7fffffff) return fail(c, KMVP_E_UNSUPPORTED, "more than 2^31 sources");
-  const int online = (c->same_points || c->opt_same_global) ? 0 : 1;  // see run_product_fastmm
+  const int online = (kernel == K_INVDIST || !(c->same_points || c->opt_same_global)) ? 1 : 0;  // see run_product_fastmm; 1/r: always
   int rc;
 
   int segments = choose_segments(c, tile_blocks, m_stages, nb_max, n_pad, SB, small ? 1 : 4, small, 2 << 20, 4096);
@@ -942,7 +942,7 @@ int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
     hipLaunchKernelGGL(pack_cfast_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream, x_raw,
                        (float*)c->xs.p, N, n_pad, D);
     hipLaunchKernelGGL(pack_cfastmm_points_kernel, dim3((unsigned)m_stages), dim3(CF_GROUP), 0, c->stream,
-                       (const float*)c->y_raw.p, (const int*)c->perm.p, (unsigned char*)c->rec.p, M, D, MODE, scale);
+                       (const float*)c->y_raw.p, (const int*)c->perm.p, (unsigned char*)c->rec.p, M, D, MODE, scale, c->j_offset);
     HIP_TRY(c, hipGetLastError());
   }
   c->packed_points_ver = c->points_ver;
@@ -966,6 +966,7 @@ int run_product_cfastmm(kmvp_ctx* c, int kernel, int sig) {
   a.tile_blocks = (int)tile_blocks;
   a.chunk_stages = std::max(1, 2 * c->opt_chunk / CF_GROUP);
   a.scale = scale;
+  a.m_total = c->m_total;
   const dim3 grid((unsigned)(tile_blocks * segments));
   const int64_t pieces = m_stages * (CF_GROUP / 32) * (MODE ? 2 : 1) * 2 * 64;
   HIP_TRY(c, mark(c, 0));
@@ -1913,11 +1914,14 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
       return run_product_fastmm(c, K_ABSEXP, sig);
     }
   }
-  if (c->dtype == KMVP_F32 && (kernel == K_GAUSSIAN || kernel == K_ABSEXP) && !c->density && c->E > 1 &&
+  // (1/r: cfast_kernel's zero rule drops the pair with the target's own index among the COINCIDENT pairs, so the targets
+  // must be the sources -- all of them, also when the sources are sharded)
+  const bool invdist_square = kernel == K_INVDIST && (c->same_points || c->opt_same_global) && c->N == c->m_total;
+  if (c->dtype == KMVP_F32 && (kernel == K_GAUSSIAN || kernel == K_ABSEXP || invdist_square) && !c->density && c->E > 1 &&
       c->D <= CFAST_MAX_D && c->centre_ver == c->points_ver &&
       (c->opt_fast == 2 || (c->opt_fast < 0 && c->E + (normalise ? 1 : 0) >= CFMM_AUTO_MIN_COLS))) {
-    // several signal columns where fastmm_kernel does not apply: exp(-r), which needs relative accuracy in s, and the
-    // Gaussian on clouds outside the radius rule -- cfast_kernel's distances, the same second product
+    // several signal columns where fastmm_kernel does not apply: exp(-r) and 1/r, which need relative accuracy in s, and
+    // the Gaussian on clouds outside the radius rule -- cfast_kernel's distances, the same second product
     c->note.clear();
     return run_product_cfastmm(c, kernel, sig);
   }

@@ -437,6 +437,53 @@ def test_fastmm_kernel_column_blocks_and_ragged_sizes(D, E, norm):
     assert np.array_equal(got2, 2.0 * got)  # powers of two go through the column scales exactly
 
 
+def test_cfastmm_inverse_distance_with_several_signal_columns(expected):
+    """1/r with an (M, E) signal on the matrix cores (bruteforce.py:8-15 + :142-153): cfastmm_kernel with
+    the per-target power-of-two scale folded into the target operand.  (1) the reference's golden same-points cases (E = 3,
+    plain and normalised), every tile count, bitwise equal across tile counts; (2) 20000 points, D = 1 .. 4, E = 16 / 33,
+    pairs 1e-6 apart and a DUPLICATED point -- its two rows must be non-finite as in the reference (coincident pair that is not
+    the target's own index: 1/0), every other row finite and within the float32 rule; (3) what auto picks."""
+    for name in ("inverse-distance-N193-M193-D3-E3-sp", "inverse-distance-N193-M193-D3-E3-nr-sp"):
+        case = next(c for c in CASES if c["name"] == name)
+        y, x, b = golden_cases.make_inputs(case)
+        truth = expected[f"{name}/f64"]
+        ref32 = expected[f"{name}/f32"].astype(np.float64)
+        outs = []
+        for tiles in (1, 2):
+            got, extra = run_plugin(case, y, x, b, "float32", fast_sqdists="centred", fast_tiles=tiles)
+            assert extra["device_kernel"] == "cfastmm_kernel" and "online shift" in extra["dispatch_note"], extra
+            assert np.array_equal(row_finite(got), row_finite(truth))
+            assert rel_err(got, truth) <= max(TOL32, 2 * rel_err(ref32, truth)), (name, tiles, rel_err(got, truth))
+            outs.append(got)
+        assert np.array_equal(outs[0], outs[1])
+    rs = np.random.RandomState(31)
+    for D, E, norm in ((3, 16, True), (3, 16, False), (1, 5, False), (2, 33, True), (4, 8, False)):
+        n = 20000
+        y = rs.rand(n, D)
+        y[100] = y[7] + 1e-6          # a nearly coincident pair: 1/r = 1e6 beside sums of order 1e4
+        y[4000] = y[12345]            # a duplicated point: rows 4000 and 12345 are 1/0 in the reference
+        b = rs.randn(n, E)
+        y32 = y.astype(np.float32).astype(np.float64)  # the arithmetic is checked on what float32 sees
+        rows = np.concatenate([rs.choice(n, size=300, replace=False), [7, 100, 4000, 12345]])
+        with np.errstate(all="ignore"):
+            want = kmvp_oracle.product(kernel="inverse-distance", source_points=y32, source_signal=b, normalize_rows=norm, rows=rows)
+            ref32 = kmvp_oracle.product(kernel="inverse-distance", source_points=y32, source_signal=b, normalize_rows=norm, rows=rows,
+                                        precision=np.float32)
+        got, extra = run_plugin(dict(kernel="inverse-distance", D=D, normalize_rows=norm), y32, None, b, "float32")
+        assert extra["device_kernel"] == "cfastmm_kernel", extra
+        fin = row_finite(want)
+        assert not fin[-2:].any() and fin[:-2].sum() >= 300
+        assert np.array_equal(row_finite(got[rows]), fin), (D, E, norm)
+        ok = fin & row_finite(ref32)
+        e, e32 = rel_err(got[rows][ok], want[ok]), rel_err(ref32[ok], want[ok])
+        assert e <= max(TOL32, 2 * e32), (D, E, norm, e, e32)
+    # targets != sources: the zero rule there is index-based without coincidence -- the centred forms do not apply
+    x = rs.rand(500, 3)
+    got, extra = run_plugin(dict(kernel="inverse-distance", D=3), y32[:3000, :3] if y32.shape[1] >= 3 else rs.rand(3000, 3), x,
+                            rs.randn(3000, 16), "float32")
+    assert extra["device_kernel"] == "lowd_kernel", extra
+
+
 CFMM_MULTI = [c for c in CASES if c["D"] <= 4 and c["kernel"] in ("gaussian", "absolute-exponential") and c["E"] > 1
               and not c["density_estimation"]]
 
