@@ -282,6 +282,9 @@ int kmvp_set_option(kmvp_ctx* c, const char* key, int64_t value) {
   } else if (k == "fast_sqdists") {
     if (value < -1 || value > 4) return fail(c, KMVP_E_INVALID, "fast_sqdists must be -1 (auto), 0, 1, 2, 3 or 4");
     c->opt_fast = (int)value;
+  } else if (k == "cellmm_shape") {
+    if (value < -1 || value > 1) return fail(c, KMVP_E_INVALID, "cellmm_shape must be -1 (by size), 0 (32x32x16) or 1 (16x16x32)");
+    c->opt_cellmm_shape = (int)value;
   } else if (k == "mfma_variant") {
     if (value != -1 && value != 0 && value != 1 && value != 4 && value != 5)
       return fail(c, KMVP_E_INVALID, "mfma_variant must be -1 (by kernel), 0, 1, 4 or 5");

@@ -336,6 +336,203 @@ cellmm_kernel(const CellmmArgs a) {
     if (h == 0) a.part[(int64_t)seg * a.n_slots + (tile0 + tt - a.tile_base) * CELL_TILE + r] = outd[tt] * inv;
 }
 
-hipError_t launch_cellmm_gaussian(int TT, const CellmmArgs& args, dim3 grid, hipStream_t stream, const char** kernel_name);
+// ------------------------------------------------------------------------------------------------------------------------
+// The same pair loop on v_mfma_f32_16x16x32_f16 (round 3).  Under the chip's power limit the 16x16x32 shape sustains more
+// than 32x32x16 at equal flop: tools/mfma_pingpong.hip, this kernel's shape (an A operand rebuilt on the VALU, 28 VALU
+// instructions per trip, random data, two waves per SIMD): 1.50 against 1.32 PFLOP/s; MI355X_MICROARCH 'DVFS give-back' 7.
+//
+// Algebra as above.  What changes is who holds what: K = 32 is TWO groups of 16 sources x the 16 monomial slots, the output
+// tile is 16 row buckets x 16 targets (rows are only buckets: a fold sums them all), so per 32 sources x 32 targets there
+// are two MFMAs (target halves) instead of one.
+//   lane l:  cc = l & 15,  kg = l >> 4 (k group 8 kg .. 8 kg + 7):  slot half h = kg & 1,  source group G = kg >> 1
+//   A operand (sources):  lane (cc, kg) holds the slots (h) of source row 16 G + cc of the tile       -- A[cc][8 kg + j]
+//   B operand (targets):  lane (cc, kg) holds the slots (h) of target cc of the half tile             -- B[8 kg + j][cc]
+//   accumulator (4 registers):  rows 4 (l >> 4) + reg, column cc; row sum = the 4 registers, then lanes l ^ 16 and l ^ 32
+//                               (v_permlane16_swap, v_permlane32_swap)
+// A wave owns the same TT tiles of 32 targets = 2 TT half tiles: 4 x 2 TT accumulator registers (64 at TT = 8, where
+// cellmm_kernel needs 128) and 4 x 2 TT operand registers (64 against 32).
+__device__ __forceinline__ float cellmm16_rows_sum(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);   // + lane ^ 16
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);  // + lane ^ 32
+}
+// sum over the wave's 32 distinct source rows (held by the lanes of rows 0 and 2 of 16; rows 1 and 3 duplicate them)
+__device__ __forceinline__ float cellmm16_sources_sum(float v) {
+  v += cellmm_dpp<0x111, 0xf>(v);  // row_shr:1
+  v += cellmm_dpp<0x112, 0xf>(v);  // row_shr:2
+  v += cellmm_dpp<0x114, 0xf>(v);  // row_shr:4
+  v += cellmm_dpp<0x118, 0xf>(v);  // row_shr:8: lane 15 of every row of 16 holds the row's sum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)) +
+         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+}
+
+template <int TT>
+__global__ void __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(TT >= 8 ? 2 : 1)))
+cellmm16_kernel(const CellmmArgs a) {
+  static_assert(!CMM_BF16, "f16 operands only");
+  constexpr int SB = CMM_STAGE_BYTES;
+  constexpr int PIECES = SB / (16 * BLOCK_THREADS);
+  constexpr float LOG2E = 1.4426950408889634f;
+  constexpr int HT = 2 * TT;  // half tiles of 16 targets
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][SB];
+
+  int tb, seg;
+  block_to_work((int)blockIdx.x, a.segments, a.tile_blocks, tb, seg);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int cc = lane & 15;
+  const int kg = lane >> 4;
+  const int h = kg & 1;
+  const int rs = 16 * (kg >> 1) + cc;  // this lane's source row in a tile of 32
+  const int64_t tile0 = a.tile_base + ((int64_t)tb * WAVES_PER_BLOCK + wave) * TT;
+
+  constexpr bool HOLD_D = TT < 8;
+  __shared__ __attribute__((aligned(16))) float dsh[HOLD_D ? 1 : WAVES_PER_BLOCK][HOLD_D ? 1 : HT][16][4];
+  float dl[HOLD_D ? HT : 1][3], cT[3], U[HT];
+  f16x8 xb[HT];
+#pragma unroll
+  for (int u = 0; u < HT; ++u) {
+    const int64_t tile = tile0 + (u >> 1);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.xd + (tile * CELL_TILE + 16 * (u & 1) + cc) * 4);
+    const f32x4 m = *reinterpret_cast<const f32x4*>(a.tmeta + tile * 4);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if constexpr (HOLD_D) dl[u][c] = v[c];
+      else if (kg == 0) dsh[wave][u][cc][c] = v[c];
+      if (u == 0) cT[c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[c])));  // one cell per wave
+    }
+    xb[u] = cellmm_target_operand(v, h);
+    U[u] = 0.f;
+  }
+
+  f32x4 acc[HT];
+  double outd[HT];
+  float vprev[HT];
+#pragma unroll
+  for (int u = 0; u < HT; ++u) {
+    outd[u] = 0.0;
+    vprev[u] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[u][k] = 0.f;
+  }
+
+  const int64_t s_begin = (int64_t)seg * a.seg_stages;
+  int64_t s_end = s_begin + a.seg_stages;
+  if (s_end > a.m_stages) s_end = a.m_stages;
+
+  f32x4 pre[PIECES];
+  auto fetch = [&](int64_t s) {
+    const unsigned char* src = a.img + s * SB;
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      pre[p] = *reinterpret_cast<const f32x4*>(src + (p * BLOCK_THREADS + (int)threadIdx.x) * 16);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      *reinterpret_cast<f32x4*>(&lds[buf][(p * BLOCK_THREADS + (int)threadIdx.x) * 16]) = pre[p];
+  };
+  if (s_begin < s_end) {
+    fetch(s_begin);
+    commit(0);
+  }
+  __syncthreads();
+
+  int key_s = -2;
+  float S0 = 0.f, S0c = 0.f;
+  float D1[3] = {0.f, 0.f, 0.f};
+
+  auto fold = [&]() {  // as in cellmm_kernel
+    const float s0 = cellmm16_sources_sum(S0) * CMM_TARGET_SCALE;
+#pragma unroll
+    for (int u = 0; u < HT; ++u) {
+      const f32x4 d = acc[u];
+      const float v = cellmm16_rows_sum((d[0] + d[1]) + (d[2] + d[3]));
+      outd[u] += (double)(U[u] * ((v - vprev[u]) + s0));
+      vprev[u] = v;
+    }
+    S0 = 0.f;
+    S0c = 0.f;
+  };
+  auto new_cell = [&](const f32x4 cs, int ks) {
+    if (key_s >= 0) fold();
+    key_s = ks;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) D1[c] = (cT[c] - cs[c]) * LOG2E;
+#pragma unroll
+    for (int u = 0; u < HT; ++u) {
+      f32x4 dv;
+      if constexpr (!HOLD_D) dv = *reinterpret_cast<const f32x4*>(&dsh[wave][u][cc][0]);
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float df;
+        if constexpr (HOLD_D) df = dl[u][c] + (cT[c] - cs[c]);
+        else df = dv[c] + (cT[c] - cs[c]);
+        s2 = fmaf(df, df, s2);
+      }
+      U[u] = kexp2(s2 * -LOG2E);
+    }
+  };
+
+  for (int64_t s = s_begin; s < s_end; ++s) {
+    const int buf = (int)((s - s_begin) & 1);
+    if (s + 1 < s_end) fetch(s + 1);
+    const unsigned char* base = &lds[buf][0];
+    const unsigned char* p_ef = base + CMM_E_OFF + rs * 16;
+    const unsigned char* p_b = base + CMM_B_OFF + rs * 4;
+    const f32x4* hdr = reinterpret_cast<const f32x4*>(base + CMM_HDR_OFF);
+#pragma unroll 1
+    for (int q = 0; q < CMM_STAGE_TILES; ++q) {
+      const f32x4 cs = hdr[q];
+      const int ks = __builtin_amdgcn_readfirstlane(__float_as_int(cs[3]));
+      if (ks < 0) break;
+      if (ks != key_s) new_cell(cs, ks);
+      // ---- A = psi_k(e_j) W_j(T) b_j for source row rs, slot half h (as cellmm_kernel)
+      const f32x4 ef = *reinterpret_cast<const f32x4*>(p_ef);
+      const float bq = *reinterpret_cast<const float*>(p_b);
+      p_ef += CELL_TILE * 16;
+      p_b += CELL_TILE * 4;
+      const f32x4 a14 = h ? f32x4{ef[2], ef[0] * ef[2], ef[2] * ef[2], ef[0] * ef[1]}
+                          : f32x4{ef[0], ef[1], ef[0] * ef[0], ef[1] * ef[1]};
+      const float a5 = h ? ef[1] * ef[2] : ef[1];
+      const float arg = fmaf(ef[0], D1[0], fmaf(ef[1], D1[1], fmaf(ef[2], D1[2], ef[3])));
+      const float wb = kexp2(arg) * bq;
+      {
+        const float yk = wb - S0c;
+        const float tk = S0 + yk;
+        S0c = (tk - S0) - yk;
+        S0 = tk;
+      }
+      const float u1 = a14[0] * wb, u2 = a14[1] * wb;
+      const f16x2 R0 = cellmm_pk(u1, u2);
+      const float c1 = (float)R0[0], c2 = (float)R0[1];
+      const f16x2 R1 = cellmm_pk(u1 - c1, u2 - c2);
+      const f16x2 R3 = cellmm_pk(a14[2] * wb, a14[3] * wb);
+      const f16x2 R2 = cellmm_pk(c1, a5 * wb);
+      i32x4 yw;
+      yw[0] = __builtin_bit_cast(int, R0);
+      yw[1] = __builtin_bit_cast(int, R1);
+      yw[2] = __builtin_bit_cast(int, R2);
+      yw[3] = __builtin_bit_cast(int, R3);
+      const f16x8 ya = __builtin_bit_cast(f16x8, yw);
+#pragma unroll
+      for (int u = 0; u < HT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ya, xb[u], acc[u], 0, 0, 0);
+    }
+    if (s + 1 < s_end) commit(buf ^ 1);
+    __syncthreads();
+  }
+  if (key_s >= 0) fold();
+
+  const double inv = (double)a.scale[1];
+#pragma unroll
+  for (int u = 0; u < HT; ++u)
+    if (kg == 0)
+      a.part[(int64_t)seg * a.n_slots + (tile0 + (u >> 1) - a.tile_base) * CELL_TILE + 16 * (u & 1) + cc] = outd[u] * inv;
+}
+
+// shape: 0 = cellmm_kernel (32x32x16), 1 = cellmm16_kernel (16x16x32)
+hipError_t launch_cellmm_gaussian(int TT, int shape, const CellmmArgs& args, dim3 grid, hipStream_t stream, const char** kernel_name);
 
 }  // namespace kmvp

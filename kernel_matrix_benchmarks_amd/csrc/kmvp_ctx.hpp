@@ -135,6 +135,7 @@ struct kmvp_ctx {
   // tuning (kmvp_set_option)
   int opt_feed = -1, opt_T = 0, opt_segments = 0, opt_chunk = 512;
   int opt_fast = -1, opt_fast_tiles = 0;  // fast_sqdists: -1 auto, 0 never, 1 always, 2 always the centred form, 3 always the cell form
+  int opt_cellmm_shape = -1;              // cellmm_kernel's MFMA shape: 0 = 32x32x16, 1 = 16x16x32 (cellmm16_kernel), -1 = by size
   int opt_mfma_variant = -1;              // bf16 path: VAR of mfma_pipe_kernel (kmvp_mfma.hpp); -1 = by kernel
   int opt_same_global = 0;                // the targets ARE the (unsharded) sources although x was passed explicitly
   int opt_partial = 0;                    // a source slice (M < M_total) may run WITHOUT a communicator: the caller sums the shards

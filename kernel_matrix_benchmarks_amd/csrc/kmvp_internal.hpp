@@ -110,7 +110,7 @@ struct CellArgs;
 hipError_t launch_cell_gaussian(int sig, int TT, const CellArgs& args, dim3 grid, hipStream_t stream,
                                 const char** kernel_name);
 struct CellmmArgs;
-hipError_t launch_cellmm_gaussian(int TT, const CellmmArgs& args, dim3 grid, hipStream_t stream, const char** kernel_name);
+hipError_t launch_cellmm_gaussian(int TT, int shape, const CellmmArgs& args, dim3 grid, hipStream_t stream, const char** kernel_name);
 struct Cell64Args;
 hipError_t launch_cell64_gaussian(int sig, const Cell64Args& args, dim3 grid, hipStream_t stream, const char** kernel_name);
 // kmvp_sort.hip: hipcub radix sort of (key, value) pairs; tmp == nullptr queries the scratch size

@@ -1442,6 +1442,9 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   if ((rc = ensure(c, c->cell_sums, (size_t)NE * n_slots * sizeof(double)))) return rc;
   double* part_main = (double*)c->part.p;
   double* part_rest = part_main + (size_t)segments * main_slots;
+  // MFMA shape: 16x16x32 (cellmm16_kernel) sustains more under the power limit, but issues twice the MFMAs per flop:
+  // 1e6 points 27.7 -> 26.6 ms, 5e5 equal, 2e5 (smaller cells' tile groups) 1.73 -> 1.96 ms (tools/cellmm_shapes.py)
+  const int shape = c->opt_cellmm_shape >= 0 ? c->opt_cellmm_shape : ((TT >= 8 && (double)c->N * (double)c->M >= 4.0e11) ? 1 : 0);
   CellmmArgs a;
   a.xd = (const float*)c->xs.p;
   a.tmeta = (const float*)c->cell_tmeta.p;
@@ -1472,7 +1475,7 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
       a.n_slots = main_slots;
       a.seg_stages = seg_stages;
       a.segments = segments;
-      le = launch_cellmm_gaussian(TT, a, dim3((unsigned)(tile_blocks * segments)), c->stream, &c->last_kernel_name);
+      le = launch_cellmm_gaussian(TT, shape, a, dim3((unsigned)(tile_blocks * segments)), c->stream, &c->last_kernel_name);
     }
     if (le == hipSuccess && rest_blocks > 0) {  // the cells' leftover tiles, two per wavefront
       a.tile_base = c->cell_n_main;
@@ -1481,7 +1484,7 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
       a.n_slots = rest_slots;
       a.seg_stages = rest_seg_stages;
       a.segments = rest_segments;
-      le = launch_cellmm_gaussian(2, a, dim3((unsigned)(rest_blocks * rest_segments)), c->stream, &c->last_kernel_name);
+      le = launch_cellmm_gaussian(2, shape, a, dim3((unsigned)(rest_blocks * rest_segments)), c->stream, &c->last_kernel_name);
     }
     if (le == hipErrorInvalidValue) return fail(c, KMVP_E_UNSUPPORTED, "fast_tiles must be 1, 2, 4 or 8");
     HIP_TRY(c, le);

@@ -1505,6 +1505,39 @@ def test_cell_kernel_worst_case_placement_in_opposite_cell_corners():
           f"auto = {extra_auto['device_kernel']}")
 
 
+def test_cellmm_kernel_both_mfma_shapes():
+    """The float32 cell form on both matrix-core shapes -- cellmm_kernel (32x32x16 f16) and cellmm16_kernel (16x16x32: two
+    groups of 16 sources per MFMA, 16 row buckets; the default at the headline size) -- for every tile count, plain /
+    density / normalised, a uniform and a clustered cloud with empty and overfull cells, targets != sources: each against
+    the float64 oracle at the float32 tolerance and against the other shape (same algebra, other summation order)."""
+    rs = np.random.RandomState(16)
+    clouds = {"uniform": rs.rand(60000, 3), "clustered": np.concatenate([rs.rand(30000, 3) * 0.2 + 0.4, rs.rand(30000, 3)])}
+    for name, y in clouds.items():
+        b = rs.randn(len(y), 1)
+        x = rs.rand(40000, 3)
+        for targets, norm, dens in ((None, False, False), (x, False, False), (None, True, False), (None, False, True)):
+            want = kmvp_oracle.product(kernel="gaussian", source_points=y, target_points=targets, source_signal=None if dens else b,
+                                       normalize_rows=norm, density_estimation=dens, rows=np.arange(0, 40000, 97))
+            for tiles in (1, 2, 4, 8):
+                outs = []
+                for shape in (0, 1):
+                    algo = MI355XProduct(kernel="gaussian", dimension=3, normalize_rows=norm, precision="float32", fast_sqdists="cells",
+                                         fast_tiles=tiles)
+                    try:
+                        algo.prepare_data(source_points=y, target_points=y if targets is None else targets,
+                                          same_points=targets is None, density_estimation=dens)
+                        algo.set_query_arguments(cellmm_shape=shape)
+                        algo.fit()
+                        algo.prepare_query(source_signal=b)
+                        algo.query()
+                        outs.append(algo.get_result())
+                        assert algo.device_kernel == "cellmm_kernel"
+                    finally:
+                        algo.done()
+                    assert rel_err(outs[-1][::97][: len(want)], want) <= TOL32, (name, tiles, shape, norm, dens)
+                assert rel_err(outs[1], outs[0]) <= 5e-7, (name, tiles, rel_err(outs[1], outs[0]))
+
+
 def test_config4_inverse_distance_one_of_eight_shards_at_full_size():
     """C4 (inverse-distance, uniform-3D, N = M = 1e7, E = 1, float32, sources sharded over 8 GPUs): what ONE of
     the 8 ranks computes -- all 1e7 targets x its 1.25e6 sources, with the zero rule of bruteforce.py:8-15 on
