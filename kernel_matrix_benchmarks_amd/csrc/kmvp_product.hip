@@ -1891,17 +1891,26 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
         t_cell = (double)cols * (double)c->cell_m_tiles *
                  (cell_ps_per_tile(c->cell_tt) * (double)c->cell_n_main + cell_ps_per_tile(2) * (double)c->cell_n_rest);
     }
+    // (the inputs of the choice go into the dispatch note: the constants were measured on one power-limited box)
+    char cost[224];
+    double t_fmm = INFINITY;
     if (fmm_ok) {
       const double tiles = std::ceil((double)c->N / FAST_TILE) * std::ceil((double)c->M / FAST_TILE);
-      const double t_fmm = tiles * ((cols + FMM_MAX_COLS - 1) / FMM_MAX_COLS) * (cols > 16 ? FMM_PS_PER_TILE_32 : FMM_PS_PER_TILE_16);
-      if (c->opt_fast == 1 || t_fmm <= t_cell) {
-        c->note.clear();
-        return run_product_fastmm(c, K_GAUSSIAN, sig);
-      }
+      t_fmm = tiles * ((cols + FMM_MAX_COLS - 1) / FMM_MAX_COLS) * (cols > 16 ? FMM_PS_PER_TILE_32 : FMM_PS_PER_TILE_16);
+    }
+    snprintf(cost, sizeof cost, " [cost model, %d columns: fastmm_kernel %.3g ms, cellmm_kernel %.3g ms (%lld + %lld target x %lld source tiles)]",
+             cols, t_fmm * 1e-9, t_cell * 1e-9, (long long)c->cell_n_main, (long long)c->cell_n_rest, (long long)c->cell_m_tiles);
+    if (fmm_ok && (c->opt_fast == 1 || t_fmm <= t_cell)) {
+      c->note.clear();
+      const int rc = run_product_fastmm(c, K_GAUSSIAN, sig);
+      if (c->opt_fast < 0) c->note += cost;
+      return rc;
     }
     if (t_cell < INFINITY) {
       c->note.clear();
-      return run_product_cellmm(c, sig);
+      const int rc = run_product_cellmm(c, sig);
+      if (c->opt_fast < 0) c->note += cost;
+      return rc;
     }
   }
   if (c->dtype == KMVP_F32 && kernel == K_ABSEXP && !c->density && c->D > CFAST_MAX_D && c->D <= FMM_MAX_D &&
