@@ -42,7 +42,8 @@ for k in sorted(per_kernel):
 want = bench.get("roofline", {}).get("kernel", "lowd_kernel")
 # every instantiation of the dominant kernel counts (the float32 cell kernels run two launches per product: whole
 # groups of eight target tiles, then the cells' leftover tiles two per wavefront): their counters are added up
-mains = [k for k in summary if want in k]
+# (cellmm_kernel names both MFMA shapes of the cell form: cellmm_kernel<TT> and cellmm16_kernel<TT>)
+mains = [k for k in summary if want in k or (want == "cellmm_kernel" and "cellmm16_kernel" in k)]
 main = mains[0] if mains else None
 if len(mains) > 1:
     merged = collections.defaultdict(float)
