@@ -762,6 +762,7 @@ def main(argv=None):
             },
             "rccl_ranks": rccl_ranks,
             "exchange": args.exchange if args.gpus > 1 else None,
+            "device_bytes": meta.get("device_bytes"),
             "max_abs_err": max_err,
             "max_rel_err": rel_err,
             "error_reference": "float64 oracle/kmvp_oracle.c (C restatement of the reference's scipy/numpy bruteforce, pinned "

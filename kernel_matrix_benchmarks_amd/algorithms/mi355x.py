@@ -271,6 +271,7 @@ class MI355XProduct(BaseProduct):
             "device_total_ms": self._ctx.last_total_ms,
             "device_kernel": self._ctx.last_kernel_name,
             "n_gpus": 1 if self.comm is None else self.comm.world,
+            "device_bytes": self._ctx.device_bytes,
             # what RCCL itself saw, and the all-reduce's share of device_total_ms (0 on one GPU)
             "rccl_ranks": self._ctx.rccl_ranks,
             "allreduce_ms": self._ctx.last_allreduce_ms,
