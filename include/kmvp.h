@@ -191,11 +191,9 @@ int kmvp_comm_init_host(kmvp_ctx* ctx, kmvp_host_allreduce_fn fn, void* user, in
  *                          float64 (cell64_kernel, E == 1): the degree-7 polynomial on the VALU;
  *                      4 = as 3 but always cell_kernel (float32);
  *                      0 = never (difference form, bruteforce.py:53-54);
- *                      -1 = auto (default): the cheapest form that is as accurate as the
- *                          difference form -- for the Gaussian on clouds of small scaled radius
- *                          3 when both clouds fill the grid cells (>= 32768 points, padding
- *                          <= 30 %), else 1 (several signal columns: 1 or 3, whichever costs less by
- *                          the tile counts); else 2 where it applies
+ *                      -1 = auto (default): the cheapest form that is as accurate as the difference form for the
+ *                          shape at hand -- which one that is: docs/DISPATCH.md (generated by asking the library),
+ *                          the rules themselves: csrc/kmvp_product.hip run_product()
  *   "same_points_global" 1 when the targets passed to kmvp_set_points are the unsharded
  *                      sources (sharded same_points): enables form 2 for inverse-distance
  *   "partial_shard"    1: a source slice (M < M_total) may be run WITHOUT a multi-rank communicator and
