@@ -26,11 +26,9 @@ static hipError_t launch_tt(int TT, const FastmmArgs& args, dim3 grid, hipStream
   return hipGetLastError();
 }
 
-static int g_online = 0;  // set by KMVP_FN for the duration of one dispatch (the context is single-threaded)
-
 template <int KS>
-static hipError_t launch_mode(int mode, int TT, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
-  if (g_online)
+static hipError_t launch_mode(int mode, int TT, int online, const FastmmArgs& args, dim3 grid, hipStream_t stream) {
+  if (online)
     return mode ? launch_tt<KS, 1, KMVP_FMM_KERNEL, 1>(TT, args, grid, stream)
                 : launch_tt<KS, 0, KMVP_FMM_KERNEL, 1>(TT, args, grid, stream);
   return mode ? launch_tt<KS, 1, KMVP_FMM_KERNEL, 0>(TT, args, grid, stream)
@@ -40,33 +38,32 @@ static hipError_t launch_mode(int mode, int TT, const FastmmArgs& args, dim3 gri
 hipError_t KMVP_FN(int KS, int mode, int TT, int online, const FastmmArgs& args, dim3 grid, hipStream_t stream,
                    const char** kernel_name) {
   if (kernel_name) *kernel_name = "fastmm_kernel";  // (ONLINE = 1 shows in the dispatch note and in the profiler's template arguments)
-  g_online = online;
   switch (KS) {
-    case 1: return launch_mode<1>(mode, TT, args, grid, stream);
-    case 2: return launch_mode<2>(mode, TT, args, grid, stream);
-    case 3: return launch_mode<3>(mode, TT, args, grid, stream);
-    case 4: return launch_mode<4>(mode, TT, args, grid, stream);
-    case 5: return launch_mode<5>(mode, TT, args, grid, stream);
-    case 6: return launch_mode<6>(mode, TT, args, grid, stream);
-    case 7: return launch_mode<7>(mode, TT, args, grid, stream);
-    case 8: return launch_mode<8>(mode, TT, args, grid, stream);
-    case 9: return launch_mode<9>(mode, TT, args, grid, stream);
-    case 10: return launch_mode<10>(mode, TT, args, grid, stream);
-    case 11: return launch_mode<11>(mode, TT, args, grid, stream);
-    case 12: return launch_mode<12>(mode, TT, args, grid, stream);
-    case 13: return launch_mode<13>(mode, TT, args, grid, stream);
-    case 14: return launch_mode<14>(mode, TT, args, grid, stream);
-    case 15: return launch_mode<15>(mode, TT, args, grid, stream);
-    case 16: return launch_mode<16>(mode, TT, args, grid, stream);
-    case 17: return launch_mode<17>(mode, TT, args, grid, stream);
-    case 18: return launch_mode<18>(mode, TT, args, grid, stream);
-    case 19: return launch_mode<19>(mode, TT, args, grid, stream);
-    case 20: return launch_mode<20>(mode, TT, args, grid, stream);
-    case 21: return launch_mode<21>(mode, TT, args, grid, stream);
-    case 22: return launch_mode<22>(mode, TT, args, grid, stream);
-    case 23: return launch_mode<23>(mode, TT, args, grid, stream);
-    case 24: return launch_mode<24>(mode, TT, args, grid, stream);
-    case 25: return launch_mode<25>(mode, TT, args, grid, stream);
+    case 1: return launch_mode<1>(mode, TT, online, args, grid, stream);
+    case 2: return launch_mode<2>(mode, TT, online, args, grid, stream);
+    case 3: return launch_mode<3>(mode, TT, online, args, grid, stream);
+    case 4: return launch_mode<4>(mode, TT, online, args, grid, stream);
+    case 5: return launch_mode<5>(mode, TT, online, args, grid, stream);
+    case 6: return launch_mode<6>(mode, TT, online, args, grid, stream);
+    case 7: return launch_mode<7>(mode, TT, online, args, grid, stream);
+    case 8: return launch_mode<8>(mode, TT, online, args, grid, stream);
+    case 9: return launch_mode<9>(mode, TT, online, args, grid, stream);
+    case 10: return launch_mode<10>(mode, TT, online, args, grid, stream);
+    case 11: return launch_mode<11>(mode, TT, online, args, grid, stream);
+    case 12: return launch_mode<12>(mode, TT, online, args, grid, stream);
+    case 13: return launch_mode<13>(mode, TT, online, args, grid, stream);
+    case 14: return launch_mode<14>(mode, TT, online, args, grid, stream);
+    case 15: return launch_mode<15>(mode, TT, online, args, grid, stream);
+    case 16: return launch_mode<16>(mode, TT, online, args, grid, stream);
+    case 17: return launch_mode<17>(mode, TT, online, args, grid, stream);
+    case 18: return launch_mode<18>(mode, TT, online, args, grid, stream);
+    case 19: return launch_mode<19>(mode, TT, online, args, grid, stream);
+    case 20: return launch_mode<20>(mode, TT, online, args, grid, stream);
+    case 21: return launch_mode<21>(mode, TT, online, args, grid, stream);
+    case 22: return launch_mode<22>(mode, TT, online, args, grid, stream);
+    case 23: return launch_mode<23>(mode, TT, online, args, grid, stream);
+    case 24: return launch_mode<24>(mode, TT, online, args, grid, stream);
+    case 25: return launch_mode<25>(mode, TT, online, args, grid, stream);
     default: return hipErrorInvalidValue;
   }
 }
