@@ -222,7 +222,16 @@ class MI355XProduct(BaseProduct):
                 res = self._ctx.get_result(self.N, self.E + 1)
                 return np.ascontiguousarray(res[:, : self.E] / res[:, self.E:])  # exp(|x_i|^2/2) cancels
             res = self._ctx.get_result(self.N, self.E)
-            return np.ascontiguousarray(res * np.exp(self._hx).reshape(-1, 1))
+            hx = self._hx.reshape(-1, 1)
+            with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+                out = res * np.exp(hx)
+                # exp(|x|^2/2 + c) alone may leave float64 where the product does not (the Gaussian factor is tiny
+                # there): those rows are put together in the log domain.  (A Gaussian factor that underflowed to 0 under
+                # an infinite target factor stays NaN: nothing is known about that entry, and 0 would be a guess.)
+                late = ~np.isfinite(out) & np.isfinite(res) & (res != 0)
+                if late.any():
+                    out = np.where(late, np.sign(res) * np.exp(np.log(np.abs(res)) + hx), out)
+            return np.ascontiguousarray(out)
         return self._ctx.get_result(self.N, self.E)
 
     # -- timed ---------------------------------------------------------------------

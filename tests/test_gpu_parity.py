@@ -180,6 +180,29 @@ def test_exp_dot_attention_matches_direct_evaluation():
     assert info["cg_converged"] == bool(info["cg_relative_residual"] <= 1.5e-8) and "cg_scaled_system_residual" in info
 
 
+def test_exp_dot_float64_products_whose_target_factor_alone_overflows():
+    """The identity route multiplies the Gaussian product by exp(|x|^2/2 + c): that factor may leave float64 where
+    exp(<x, y>) itself does not (found by tools/fuzz_parity.py, seed 77 case 1041).  Those rows are assembled in the log
+    domain; the results must be finite and match the direct evaluation."""
+    rs = np.random.RandomState(1041)
+    D, N, M, E = 40, 300, 33, 5
+    y, x, b = rs.rand(M, D) * 6.6, rs.rand(N, D) * 6.6, rs.randn(M, E)
+    assert 0.5 * (x * x).sum(axis=1).max() + 0.5 * (y * y).sum(axis=1).max() > 780 > 700 > (x @ y.T).max()
+    algo = MI355XProduct(kernel="exp-dot", dimension=D, precision=np.float64)
+    try:
+        algo.prepare_data(source_points=y, target_points=x, same_points=False)
+        algo.fit()
+        algo.prepare_query(source_signal=b)
+        algo.query()
+        got = algo.get_result()
+    finally:
+        algo.done()
+    want = kmvp_oracle.exp_dot_product(source_points=y, target_points=x, source_signal=b)
+    mass = kmvp_oracle.exp_dot_product(source_points=y, target_points=x, source_signal=np.abs(b))
+    assert np.isfinite(want).all() and np.isfinite(got).all()
+    assert float((np.abs(got - want) / mass).max()) <= 1e-9  # logits ~700 carry 700 x 1e-16 x a few roundings
+
+
 def test_exp_dot_native_kernel_has_no_range_limit():
     """The online-max formulation (include/kmvp.h kmvp_expdot[_norm]): key norms |y|^2/2 up to ~500
     and logits <x, y> of several hundred either sign, ragged N != M, targets != sources.  Softmax rows against the direct

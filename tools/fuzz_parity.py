@@ -31,14 +31,27 @@ def one_case(rs):
     form = FORMS[rs.randint(len(FORMS))]
     tiles = int(rs.choice([0, 0, 1, 2, 4, 8]))
     spread = float(rs.choice([0.3, 1.0, 1.0, 3.0]))
+    # targets displaced from the sources by this many kernel lengths (targets != sources only): every kernel value of a
+    # row is then tiny, and each ROW is held to its own mass sum_j k |b_j| (the per-target shift of the f16-split kernels)
+    offset = 0.0 if same else float(rs.choice([0.0, 0.0, 0.0, 2.0, 4.0, 7.0]))
+    if rs.rand() < 0.12:  # exp<x, y>: the online-max kernel (float32, D <= 64) or the Gaussian identity
+        kernel, form, tiles, dens = "exp-dot", None, 0, False
+        precision = ["float32", "float32", "float64"][rs.randint(3)]
     return dict(kernel=kernel, D=D, E=E, N=N, M=M, same=same, norm=norm, dens=dens, precision=precision, form=form,
-                tiles=tiles, spread=spread)
+                tiles=tiles, spread=spread, offset=offset)
 
 
 def run_case(c, rs):
     D, E, N, M = c["D"], c["E"], c["N"], c["M"]
     y = rs.rand(M, D) * c["spread"] / np.sqrt(D / 3.0)
     x = None if c["same"] else rs.rand(N, D) * c["spread"] / np.sqrt(D / 3.0)
+    if x is not None and c["offset"] > 0 and c["kernel"] != "exp-dot":
+        u = rs.randn(D)
+        x = x + c["offset"] * u / np.linalg.norm(u)
+    if c["kernel"] == "exp-dot":  # logits of a few units to a few hundred
+        g = float(rs.choice([1.0, 3.0, 10.0]))
+        y = y * g
+        x = None if x is None else x * g
     b = None if c["dens"] else rs.randn(M, E)
     if c["precision"] != "float64":
         # the inputs as the working precision sees them (bruteforce.py:97-99 casts them first): the sweep checks the
@@ -63,6 +76,8 @@ def run_case(c, rs):
     if N * M > 20_000_000:  # the numpy oracle on a row sample
         rows = np.sort(rs.choice(N, size=256, replace=False))
         got = got[rows]
+    if c["kernel"] == "exp-dot":
+        return kname, check_exp_dot(c, got, y, x, b, rows)
     want = kmvp_oracle.product(kernel=c["kernel"], source_points=y, target_points=x, source_signal=b,
                                normalize_rows=c["norm"], density_estimation=c["dens"], rows=rows)
     finite = np.isfinite(want).all(axis=-1) if want.ndim > 1 else np.isfinite(want)
@@ -82,11 +97,35 @@ def run_case(c, rs):
                                        normalize_rows=c["norm"], density_estimation=c["dens"], rows=rows,
                                        precision=np.float32, fast_sqdists=True)
         finite = finite & (np.isfinite(ref_fast).all(axis=-1) if ref_fast.ndim > 1 else np.isfinite(ref_fast))
+    if c["offset"] > 0 and c["norm"] and c["precision"] != "float64":
+        # a float32 denominator below the float32 range is 0 and the row 0/0, in the reference's float32 run as here
+        # (the kernels with a per-target shift do better; the difference form does not have to)
+        den = kmvp_oracle.product(kernel=c["kernel"], source_points=y, target_points=x, density_estimation=True, rows=rows)
+        finite = finite & (den.reshape(len(den), -1) > 1e-30).all(axis=-1)
     if not np.array_equal(gf & finite, finite):
         return kname, f"non-finite rows differ: {int((gf & finite).sum())} finite of {int(finite.sum())} expected"
     if not finite.any():
         return kname, None
     scale = np.abs(want[finite]).max()
+    if c["offset"] > 0 and not c["norm"] and scale > 0:
+        # displaced targets: row by row against the row's own mass (a global yardstick would hide a row that lost its
+        # digits); the float32 kernels flush rows below the float32 range to zero, those rows are left out
+        mass = kmvp_oracle.product(kernel=c["kernel"], source_points=y, target_points=x,
+                                   source_signal=None if b is None else np.abs(b), density_estimation=c["dens"], rows=rows)
+        live = finite & ((mass > 1e-30).all(axis=-1) if mass.ndim > 1 else mass > 1e-30)
+        if c["precision"] == "float64":
+            live = finite
+        if not live.any():
+            return kname, None
+        rel = float((np.abs(got[live] - want[live]) / np.maximum(mass[live], 1e-300)).max())
+        tol = 1e-11 if c["precision"] == "float64" else (2e-4 if c["kernel"] == "inverse-distance" else 2e-5)
+        if forced_expanded:
+            tol = max(tol, 2.0 * float((np.abs(ref_fast[live].astype(np.float64) - want[live]) / np.maximum(mass[live], 1e-300)).max()))
+        if rel > tol and c["precision"] != "float64":
+            ref32 = kmvp_oracle.product(kernel=c["kernel"], source_points=y, target_points=x, source_signal=b,
+                                        density_estimation=c["dens"], rows=rows, precision=np.float32)
+            tol = max(tol, 2.0 * float((np.abs(ref32[live] - want[live]) / np.maximum(mass[live], 1e-300)).max()))
+        return kname, (None if rel <= tol else f"row-relative error {rel:.3e} > {tol:.0e}")
     err = float(np.abs(got[finite] - want[finite]).max() / scale) if scale > 0 else float(np.abs(got[finite]).max())
     tol = 1e-11 if c["precision"] == "float64" else 2e-5
     if c["kernel"] == "inverse-distance" and c["precision"] != "float64":
@@ -102,6 +141,31 @@ def run_case(c, rs):
         ok32 = finite & (np.isfinite(ref32).all(axis=-1) if ref32.ndim > 1 else np.isfinite(ref32))
         tol = max(tol, 2.0 * float(np.abs(ref32[ok32] - want[ok32]).max() / scale))
     return kname, (None if err <= tol else f"error {err:.3e} > {tol:.0e}")
+
+
+def check_exp_dot(c, got, y, x, b, rows):
+    """exp<x, y> against direct float64 evaluation (oracle/kmvp_oracle.py exp_dot_product), rows by their own mass."""
+    xt = y if x is None else x
+    if rows is not None:
+        xt = xt[rows]
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = kmvp_oracle.exp_dot_product(source_points=y, target_points=xt, source_signal=b, normalize_rows=c["norm"])
+        mass = want if c["norm"] else kmvp_oracle.exp_dot_product(source_points=y, target_points=xt, source_signal=np.abs(b))
+    if got.shape != want.shape:
+        return f"shape {got.shape} != {want.shape}"
+    live = np.isfinite(want).all(axis=-1) & np.isfinite(mass).all(axis=-1)
+    if c["precision"] != "float64":  # results beyond the float32 range are not representable in the working precision
+        live &= (np.abs(mass) < 1e37).all(axis=-1)
+    if not live.any():
+        return None
+    if not np.isfinite(got[live]).all():
+        return f"non-finite rows: {int((~np.isfinite(got[live]).all(axis=-1)).sum())} of {int(live.sum())}"
+    yard = np.abs(want[live]).max() if c["norm"] else np.maximum(np.abs(mass[live]), 1e-300)
+    rel = float((np.abs(got[live] - want[live]) / yard).max())
+    # float32: a logit carries ~1e-7 of the largest |x| |y| as ABSOLUTE error, which is a relative error of the weight
+    lmax = float(np.sqrt((xt * xt).sum(axis=1).max() * (y * y).sum(axis=1).max()))
+    tol = 1e-10 * max(1.0, lmax) if c["precision"] == "float64" else 2e-5 + 5e-7 * lmax
+    return None if rel <= tol else f"exp-dot error {rel:.3e} > {tol:.0e}"
 
 
 def sweep(cases, seed, verbose=True):
