@@ -97,6 +97,21 @@ def run_case(c, rs):
                                        normalize_rows=c["norm"], density_estimation=c["dens"], rows=rows,
                                        precision=np.float32, fast_sqdists=True)
         finite = finite & (np.isfinite(ref_fast).all(axis=-1) if ref_fast.ndim > 1 else np.isfinite(ref_fast))
+        # ... and where the row's closest pair is resolved at all by an expansion around one centre: its s carries
+        # ~1e-7 (|x - c|^2 + |y - c|^2) of absolute error, so a pair closer than that may come out as s <= 0 in one
+        # float32 arithmetic and not in another (the reference's own run takes sqrt of negative numbers there)
+        xt = y if x is None else x
+        xt = xt if rows is None else xt[rows]
+        cen = np.concatenate([y, xt]).mean(axis=0)
+        r2 = ((xt - cen) ** 2).sum(axis=1).max() + ((y - cen) ** 2).sum(axis=1).max()
+        smin = np.full(len(xt), np.inf)
+        for j0 in range(0, len(y), 4096):
+            yc, xc = y[j0:j0 + 4096] - cen, xt - cen  # (float64: the expanded form is exact enough for this bound)
+            d = np.maximum((xc * xc).sum(axis=1)[:, None] + (yc * yc).sum(axis=1)[None, :] - 2.0 * (xc @ yc.T), 0.0)
+            if x is None:
+                d[d <= 1e-14 * r2] = np.inf  # the pair the index rule drops
+            smin = np.minimum(smin, d.min(axis=1))
+        finite = finite & (smin > 1e-5 * r2)
     if c["offset"] > 0 and c["norm"] and c["precision"] != "float64":
         # a float32 denominator below the float32 range is 0 and the row 0/0, in the reference's float32 run as here
         # (the kernels with a per-target shift do better; the difference form does not have to)
@@ -119,6 +134,11 @@ def run_case(c, rs):
             return kname, None
         rel = float((np.abs(got[live] - want[live]) / np.maximum(mass[live], 1e-300)).max())
         tol = 1e-11 if c["precision"] == "float64" else (2e-4 if c["kernel"] == "inverse-distance" else 2e-5)
+        if c["precision"] != "float64" and c["kernel"] != "inverse-distance":
+            # float32 rounds s itself by 6e-8 s, which is an ABSOLUTE error of the exponent: s up to ~150 here
+            xt = x if rows is None else x[rows]
+            smax = float(((np.maximum(xt.max(axis=0), y.max(axis=0)) - np.minimum(xt.min(axis=0), y.min(axis=0))) ** 2).sum())
+            tol += 3e-7 * (smax if c["kernel"] == "gaussian" else np.sqrt(smax))
         if forced_expanded:
             tol = max(tol, 2.0 * float((np.abs(ref_fast[live].astype(np.float64) - want[live]) / np.maximum(mass[live], 1e-300)).max()))
         if rel > tol and c["precision"] != "float64":
