@@ -557,6 +557,20 @@ def roofline_of(W, kname, k_ms, world=1):
         tiles32 = -(-n // 32) * -(-my_sources // 32) * (-(-(E + (1 if W.normalize else 0)) // 32))
         r["issue_bound_ms"] = tiles32 * 331.0 / 1024 / 2.4e9 * 1e3
         r["issue_bound_frac"] = r["issue_bound_ms"] / k_ms
+    if kname == "cfast_kernel":
+        # per 32 x 32 tile of pairs a wave issues 16 transcendentals (9.76 cycles each with >= 4 waves per SIMD,
+        # profiles/r02_micro_trans_rates_f16.txt), 16 v_fmac_f32 (3.35) and 2 MFMAs (8 issue cycles); packing the FMAs
+        # into v_pk_fma_f32 (5.68 per two) changed nothing measurable (LAB_NOTES I.8)
+        per_tile = (32 if kernel_uses_two_transcendentals(W.kernel) else 16) * 9.76 + 16 * 3.35 + 2 * 8
+        r["issue_bound_ms"] = (-(-n // 32)) * (-(-my_sources // 32)) * per_tile / 1024 / 2.4e9 * 1e3
+        r["issue_bound_frac"] = r["issue_bound_ms"] / k_ms
+    if kname == "mfma_pipe_kernel" and W.kernel == "absolute-exponential":
+        # 16 v_sqrt + 16 v_exp (9.76), 16 v_add for the denominators (3.35), 8 v_cvt_pk_bf16 (5.42) and the issue of
+        # KS + 2 NT MFMAs (8) per 32 x 32 tile of pairs
+        ks, nt = -(-(D + 6) // 16), -(-E // 32)
+        per_tile = 32 * 9.76 + 16 * 3.35 + 8 * 5.42 + (ks + 2 * nt) * 8
+        r["issue_bound_ms"] = (-(-n // 32)) * (-(-my_sources // 32)) * per_tile / 1024 / 2.4e9 * 1e3
+        r["issue_bound_frac"] = r["issue_bound_ms"] / k_ms
     if kname == "cell_kernel":
         r["nonpacked_fp32_ceiling_tflops"] = NONPACKED_FP32_FMA_TFLOPS
         r["mfma_frac"] = 32.0 * shard_pairs / (k_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
@@ -565,6 +579,11 @@ def roofline_of(W, kname, k_ms, world=1):
         r["source_stream_GBps"] = tiles * float(my_sources) * (D + E) * 4 / (k_ms * 1e-3) / 1e9
         r["source_stream_frac_of_hbm_peak"] = r["source_stream_GBps"] / PEAK_HBM_GBPS
     return r
+
+
+def kernel_uses_two_transcendentals(kernel):
+    """exp(-r) takes a square root and an exponential per pair; the Gaussian and 1/r take one instruction."""
+    return kernel == "absolute-exponential"
 
 
 def measure_other_configs(args, device, np):
