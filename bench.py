@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the on-the-fly kernel matrix-vector product on MI355X: point-pair interactions per second.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|4shard|5|attn]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|4shard|5|attn|softmax]
 
 ``--config`` names a BASELINE.json config (default 2, the one the headline metric is quoted on):
 
@@ -17,7 +17,10 @@
   5       Gaussian solver K b = a, N = M = 1e5, D = 3, float64, CG with the HIP matvec as operator, to a
           relative residual of 1e-6.  One step = one solve; pairs = (iterations + 1 products) x N^2.
 
-The default run (config 2, one GPU) also measures configs 3, 4shard, 5 and the D = 3 attention shape in the same
+  softmax (not a BASELINE config) softmax attention exp(<x,y>) (README.md:51-59), row-normalised, x = y ~ N(0,1)^64,
+          N = M = 65536, E = 64, bf16 MFMA tiles with the per-target online shift (kmvp_mfma.hpp).
+
+The default run (config 2, one GPU) also measures configs 3, softmax, 4shard, 5 and the D = 3 attention shape in the same
 process AFTER the timed region of the headline line, a few steps each, and appends them as ``other_configs``
 (``--no-other-configs`` skips that).
 
@@ -59,7 +62,7 @@ SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS = 1570.0   # tools/mfma_stream.hip: 1.50-1
 NONPACKED_FP32_FMA_TFLOPS = 147.4                # tools/valu_peak.hip: 7.37e13 v_fma_f32 lane-ops/s x 2
 
 KERNELS = {"gaussian": "gaussian", "absexp": "absolute-exponential", "invdist": "inverse-distance"}
-FULL_SIZE = {"2": 1000000, "3": 65536, "4": 10000000, "4shard": 10000000, "5": 100000, "attn": 100000}
+FULL_SIZE = {"2": 1000000, "3": 65536, "4": 10000000, "4shard": 10000000, "5": 100000, "attn": 100000, "softmax": 65536}
 
 # Algorithmic work per pair of each pair-loop kernel, on the unit that bounds it.
 #   cellmm_kernel: one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs -> 2 x 16 = 32 matrix flop per pair
@@ -111,7 +114,7 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None, help="default: 10 (config 2, 3), 3 (4shard), 2 (4, 5)")
     p.add_argument("--warmup", type=int, default=None, help="default: 2 (config 2), 50 (the millisecond launches of 3, attn), 1 otherwise")
-    p.add_argument("--config", choices=["2", "3", "4", "4shard", "5", "attn"], default="2",
+    p.add_argument("--config", choices=["2", "3", "4", "4shard", "5", "attn", "softmax"], default="2",
                    help="BASELINE config; attn (not a BASELINE config): D = 3 Gaussian attention with 16 value channels at "
                         "N = M = 1e5, VERDICT r1 item 9")
     p.add_argument("--points", dest="n", type=float, default=None, help="override N = M of the config (not a BASELINE run)")
@@ -219,6 +222,23 @@ def launch_ranks(args, argv):
 
 # ---------------------------------------------------------------------------------------------------------
 # CPU baselines (test infrastructure: oracle/)
+
+def cpu_exp_dot(y64, b64, budget_s, normalize_rows, np):
+    """exp(<x,y>) has no reference plugin (README.md:51-59 only): the CPU figure is the direct numpy evaluation
+    (oracle/kmvp_oracle.py exp_dot_product: GEMM + exp + GEMM, float64) on a row sample sized for the budget."""
+    import kmvp_oracle
+
+    n = y64.shape[0]
+    t0 = time.perf_counter()
+    kmvp_oracle.exp_dot_product(source_points=y64, target_points=y64[:256], source_signal=b64, normalize_rows=normalize_rows)
+    probe = time.perf_counter() - t0
+    rows = int(min(n, max(256, 256 * budget_s / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    kmvp_oracle.exp_dot_product(source_points=y64, target_points=y64[:rows], source_signal=b64, normalize_rows=normalize_rows)
+    dt = time.perf_counter() - t0
+    return {"value": rows * float(n) / dt, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{rows} of {n} target rows x all {n} sources, float64 numpy (GEMM on the BLAS threads, exp on one), {dt:.1f} s"}
+
 
 def cpu_port(kernel, y64, b64, precision, budget_s, normalize_rows=False, x64=None, shard=None):
     """oracle/kmvp_oracle.c (C, OpenMP over target rows) on a bounded sample of target rows of the same workload."""
@@ -336,6 +356,9 @@ class Workload:
         elif cfg == "attn":
             self.kernel, self.precision, self.normalize = "gaussian", "float32", True
             self.E = 16
+        elif cfg == "softmax":
+            self.kernel, self.precision, self.normalize = "exp-dot", "bfloat16", True
+            self.D, self.E = 64, 64
         elif cfg in ("4", "4shard"):
             self.kernel, self.precision = "inverse-distance", "float32"
         else:
@@ -346,6 +369,8 @@ class Workload:
         y = rs.rand(n, D)
         if cfg == "3":
             y = y / np.sqrt(D)  # otherwise |x - y| ~ 3.3 and every weight is ~ e^-3.3
+        if cfg == "softmax":
+            y = rs.randn(n, D)  # queries = keys ~ N(0, 1): logits <x, y> ~ N(0, 64), |y|^2/2 spans ~50 (layer-normed heads)
         b = rs.randn(n, E)
         self.y, self.b = y, b
         self.pairs = float(n) * float(n)
@@ -453,6 +478,8 @@ class Workload:
                  f"E={E}, bf16 MFMA tiles, same_points",
             "attn": f"not a BASELINE config (VERDICT r1 item 9): Gaussian attention (row-normalised), uniform-3D, "
                     f"N=M={n}, D=3, E={E} value channels, float32, same_points",
+            "softmax": f"not a BASELINE config (SURVEY 8f-4, README.md:51-59): softmax attention exp(<x,y>) (row-normalised), "
+                       f"x = y ~ N(0, 1)^D, N=M={n}, D={D}, E={E}, bf16 MFMA tiles with the per-target online shift",
             "4": f"BASELINE config 4: inverse-distance product, uniform-3D, N=M={n}, D=3, E=1, float32, sources "
                  f"sharded over {gpus} GPU(s)",
             "4shard": f"BASELINE config 4, one of 8 source shards on one GPU: {n} targets x {self.my_sources()} sources "
@@ -500,6 +527,10 @@ def error_leg(W, a, meta):
         lo, hi = W.shard
         truth, _ = c_oracle.product(kernel=W.kernel, source_points=W.y[lo:hi], target_points=W.y, source_signal=W.b[lo:hi],
                                     rows=rows, j_offset=lo, M_total=W.n, raw_sums=True)
+    elif W.kernel == "exp-dot":
+        import kmvp_oracle  # (the C restatement has the reference's three kernels; exp(<x,y>) is checked by direct evaluation)
+
+        truth = kmvp_oracle.exp_dot_product(source_points=W.y, target_points=W.y[rows], source_signal=W.b, normalize_rows=W.normalize)
     else:
         truth = c_oracle.product(kernel=W.kernel, source_points=W.y, source_signal=W.b, rows=rows, normalize_rows=W.normalize)
     norms = np.sqrt(np.sum((a[rows] - truth) ** 2, axis=-1))  # plotting/metrics.py:53-56
@@ -515,14 +546,15 @@ def roofline_of(W, kname, k_ms, world=1):
     if kname.startswith("mfma"):
         bound, fpp, peak, basis = ("mfma", 2.0 * (D + E + 1), PEAK_F16_MFMA_TFLOPS,
                                    "2 (D + E + 1) matrix flop per pair (distances + P [b | 1], SURVEY 8d) vs the dense "
-                                   "bf16 MFMA peak; the transcendental rate bounds it equally (one sqrt + one exp2 per pair)")
+                                   "bf16 MFMA peak; the transcendental rate bounds it equally (" +
+                                   ("one sqrt + one exp2" if W.kernel == "absolute-exponential" else "one exp2") + " per pair)")
     else:
         bound, fpp, peak, basis = ROOF.get(kname, ROOF["lowd_kernel"])
     achieved = fpp * shard_pairs / (k_ms * 1e-3) / 1e12
     cfg = W.cfg
     tag = {"2": f"{'gaussian' if W.kernel == 'gaussian' else W.kernel}_1e6_{'f32' if W.precision == 'float32' else 'f64'}",
            "3": "c3_absexp_bf16", "4": "c4_invdist_1e7_f32", "4shard": "c4shard_invdist_f32", "5": "c5_gaussian_1e5_f64",
-           "attn": "attn_gaussian_1e5_e16_f32"}[cfg]
+           "attn": "attn_gaussian_1e5_e16_f32", "softmax": "softmax_expdot_bf16"}[cfg]
     traffic, traffic_source = traffic_from_profile(kname, tag) if n == FULL_SIZE[cfg] and world == 1 else (None, None)
     esize = 8 if W.precision == "float64" else (2 if W.precision == "bfloat16" else 4)
     r = {
@@ -564,11 +596,11 @@ def roofline_of(W, kname, k_ms, world=1):
         per_tile = (32 if kernel_uses_two_transcendentals(W.kernel) else 16) * 9.76 + 16 * 3.35 + 2 * 8
         r["issue_bound_ms"] = (-(-n // 32)) * (-(-my_sources // 32)) * per_tile / 1024 / 2.4e9 * 1e3
         r["issue_bound_frac"] = r["issue_bound_ms"] / k_ms
-    if kname == "mfma_pipe_kernel" and W.kernel == "absolute-exponential":
-        # 16 v_sqrt + 16 v_exp (9.76), 16 v_add for the denominators (3.35), 8 v_cvt_pk_bf16 (5.42) and the issue of
-        # KS + 2 NT MFMAs (8) per 32 x 32 tile of pairs
-        ks, nt = -(-(D + 6) // 16), -(-E // 32)
-        per_tile = 32 * 9.76 + 16 * 3.35 + 8 * 5.42 + (ks + 2 * nt) * 8
+    if kname == "mfma_pipe_kernel" and W.kernel in ("absolute-exponential", "exp-dot"):
+        # 16 v_sqrt + 16 v_exp (9.76; exp(<x,y>): the 16 v_exp only), 16 v_add for the denominators (3.35), 8 v_cvt_pk_bf16
+        # (5.42) and the issue of KS + 2 NT MFMAs (8) per 32 x 32 tile of pairs
+        ks, nt = -(-(D + (6 if W.kernel == "absolute-exponential" else 3)) // 16), -(-E // 32)
+        per_tile = (32 if W.kernel == "absolute-exponential" else 16) * 9.76 + 16 * 3.35 + 8 * 5.42 + (ks + 2 * nt) * 8
         r["issue_bound_ms"] = (-(-n // 32)) * (-(-my_sources // 32)) * per_tile / 1024 / 2.4e9 * 1e3
         r["issue_bound_frac"] = r["issue_bound_ms"] / k_ms
     if kname == "cell_kernel":
@@ -592,7 +624,7 @@ def measure_other_configs(args, device, np):
     # (the short launches need a long warm-up: after the idle seconds of the CPU baseline the chip takes ~50 ms of work to
     # return to its steady clock -- config 3: 1.30 ms per launch after 2 warm-up steps, 1.18 after 40, 1.10-1.12 in steady
     # state; profiles/r03_c3_variants.txt)
-    plan = (("3", 20, 50), ("attn", 20, 50), ("4shard", 2, 1), ("5", 1, 1))
+    plan = (("3", 20, 50), ("softmax", 20, 50), ("attn", 20, 50), ("4shard", 2, 1), ("5", 1, 1))
     out = {}
     for cfg, steps, warmup in plan:
         t_start = time.time()
@@ -632,7 +664,7 @@ def measure_other_configs(args, device, np):
         except Exception as e:  # the headline line must still be printed
             entry = {"error": f"{type(e).__name__}: {e}"}
         entry["wall_s"] = round(time.time() - t_start, 2)
-        out["C" + cfg if cfg != "attn" else "attn"] = entry
+        out["C" + cfg if cfg not in ("attn", "softmax") else cfg] = entry
     return out
 
 
@@ -652,7 +684,7 @@ def main(argv=None):
     # every rank checks the launch shape BEFORE anything touches a GPU, with a message that says what to change
     if distributed and world != args.gpus:
         raise SystemExit(f"[rank {rank}] --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
-    if args.config in ("4shard", "5", "3", "attn") and args.gpus > 1:
+    if args.config in ("4shard", "5", "3", "attn", "softmax") and args.gpus > 1:
         raise SystemExit(f"--config {args.config} is a single-GPU measurement")
     # the host driver of this pool only supports dmabuf IPC (RCCL across processes needs it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -702,8 +734,8 @@ def main(argv=None):
             dist.barrier()
 
     cfg = args.config
-    steps = args.steps if args.steps is not None else {"2": 10, "3": 10, "4shard": 3, "4": 2, "5": 2, "attn": 10}[cfg]
-    warmup = args.warmup if args.warmup is not None else {"2": 2, "3": 50, "attn": 50}.get(cfg, 1)
+    steps = args.steps if args.steps is not None else {"2": 10, "3": 10, "4shard": 3, "4": 2, "5": 2, "attn": 10, "softmax": 10}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"2": 2, "3": 50, "attn": 50, "softmax": 50}.get(cfg, 1)
 
     W = Workload(cfg, args, device, comm, np, n=args.n, sqdists=args.sqdists, kernel_arg=args.kernel,
                  precision_arg=args.precision)
@@ -784,8 +816,11 @@ def main(argv=None):
             "device_bytes": meta.get("device_bytes"),
             "max_abs_err": max_err,
             "max_rel_err": rel_err,
-            "error_reference": "float64 oracle/kmvp_oracle.c (C restatement of the reference's scipy/numpy bruteforce, pinned "
-                               "by tests/golden), 256 sampled rows; all rows: tests/test_gpu_parity.py::test_config2_*",
+            "error_reference": ("direct float64 numpy evaluation of exp(<x,y>) (oracle/kmvp_oracle.py exp_dot_product; PARITY "
+                                "UNPINNED: the kernel exists in the reference's README only), 256 sampled rows"
+                                if kernel == "exp-dot" else
+                                "float64 oracle/kmvp_oracle.c (C restatement of the reference's scipy/numpy bruteforce, pinned "
+                                "by tests/golden), 256 sampled rows; all rows: tests/test_gpu_parity.py::test_config2_*"),
             "roofline": r,
         }
         if solver:
@@ -797,6 +832,8 @@ def main(argv=None):
             if W.shard is not None:
                 lo, hi = W.shard
                 base = cpu_port(kernel, W.y[lo:hi], W.b[lo:hi], "float32", args.cpu_seconds, x64=W.y, shard=(lo, n))
+            elif kernel == "exp-dot":
+                base = cpu_exp_dot(W.y, W.b, args.cpu_seconds, W.normalize, np)
             else:
                 base = cpu_port(kernel, W.y, W.b, "float32" if precision == "bfloat16" else precision, args.cpu_seconds,
                                 normalize_rows=W.normalize)

@@ -108,10 +108,11 @@ int kmvp_absexp_norm(kmvp_ctx* ctx);
 int kmvp_invdist(kmvp_ctx* ctx);
 int kmvp_invdist_norm(kmvp_ctx* ctx);
 /* k(x, y) = exp(<x, y>): the attention kernel the reference's README defines (README.md:51-59; no reference plugin
- * computes it: parity unpinned).  float32, D <= 64, a signal must be set (density estimation: pass ones).  S = X Y^T
- * comes straight from the matrix cores (3-way split bf16 operands, fp32 accuracy), the kernel values are taken relative
- * to a per-target running maximum exponent (flash-attention recurrence with integer exponents: kmvp_fastmm.hpp) and
- * leave the pair loop as (mantissa sums, exponent) pairs, so that
+ * computes it: parity unpinned).  float32 at D <= 64 or bfloat16 at D <= 141, E <= 128; a signal must be set (density
+ * estimation: pass ones).  S = X Y^T comes straight from the matrix cores (float32: 3-way split bf16 operands, fp32
+ * accuracy, kmvp_fastmm.hpp; bfloat16: plain bf16 operands and a bf16 second product, kmvp_mfma.hpp), the kernel values are
+ * taken relative to a per-target running exponent (flash-attention recurrence with integer exponents) and leave the pair
+ * loop as (mantissa sums, exponent) pairs, so that
  *   kmvp_expdot_norm  softmax attention  a_i = sum_j e^<x_i,y_j> b_j / sum_j e^<x_i,y_j>   has NO range limit on <x, y>;
  *   kmvp_expdot       plain product: overflows to inf exactly where exp(<x, y>) leaves the float64 range.
  * Sharded: all-reduce(min) of the exponents, then the usual all-reduce(sum).  Other dtypes / D: KMVP_E_UNSUPPORTED

@@ -30,11 +30,11 @@ SUPPORTED_KERNELS = ("gaussian", "absolute-exponential", "inverse-distance", "ex
 # "exp-dot": k(x, y) = exp(<x, y>), the transformer attention kernel the reference's README defines
 # (README.md:51-59) but its plugins do not implement (bruteforce.py:18-22 has the other three): parity
 # unpinned, checked against a direct numpy evaluation only (the tests' exp_dot_product).  Two routes:
-#  * NATIVE (float32 / float16 inputs, D <= 64; include/kmvp.h kmvp_expdot[_norm]): S = X Y^T straight from the
-#    matrix cores, kernel values relative to a per-target running maximum exponent (the flash-attention
+#  * NATIVE (float32 / float16 inputs at D <= 64, bfloat16 at D <= 141; include/kmvp.h kmvp_expdot[_norm]): S = X Y^T
+#    straight from the matrix cores, kernel values relative to a per-target running exponent (the flash-attention
 #    recurrence), partial sums merged as (mantissa, exponent) pairs -- softmax attention has NO range limit on
 #    <x, y>; plain products overflow where exp(<x, y>) leaves float64, as numpy's would.
-#  * IDENTITY (float64, bfloat16, D > 64, and the solver):
+#  * IDENTITY (float64, float32 at D > 64, and the solver):
 #        exp(<x, y>) = exp(|x|^2 / 2) * exp(-|x/sqrt2 - y/sqrt2|^2) * exp(|y|^2 / 2)
 #    i.e. a GAUSSIAN product on the points / sqrt(2) with the signal weighted by w_j = exp(|y_j|^2/2 - c)
 #    (c = max_j |y_j|^2/2, so w <= 1) -- every Gaussian kernel of the library serves it.  Row-normalised: (K (w b)) /
@@ -43,6 +43,7 @@ SUPPORTED_KERNELS = ("gaussian", "absolute-exponential", "inverse-distance", "ex
 #    (EXPDOT_IDENTITY_SPREAD), NotImplementedError beyond it -- never a silent zero weight.
 SQRT_HALF = 0.7071067811865476
 EXPDOT_NATIVE_MAX_D = 64
+EXPDOT_NATIVE_MAX_D_BF16 = 141  # 16 * 9 k-steps - 3 operand columns (kmvp_mfma.hpp MFMA_DOT_AUG)
 # largest spread max_j |y_j|^2/2 - min_j |y_j|^2/2 the identity route accepts: the smallest weight is exp(-spread);
 # float32 / bfloat16 (8-bit exponent): e^-80 = 2^-115 is still a normal number; float64: e^-700
 EXPDOT_IDENTITY_SPREAD = {"float32": 80.0, "float64": 700.0}
@@ -118,7 +119,9 @@ class MI355XProduct(BaseProduct):
         self.density_estimation = bool(density_estimation)
         self._dot_note = ""
         if self._dot:
-            self._dot_native = (self._dtype_code == _lib.KMVP_F32 and np.asarray(source_points).shape[1] <= EXPDOT_NATIVE_MAX_D)
+            d_in = np.asarray(source_points).shape[1]
+            self._dot_native = ((self._dtype_code == _lib.KMVP_F32 and d_in <= EXPDOT_NATIVE_MAX_D) or
+                                (self._dtype_code == _lib.KMVP_BF16 and d_in <= EXPDOT_NATIVE_MAX_D_BF16))
             self._device_kernel_fn = "exp-dot" if self._dot_native else "gaussian"
         if self._dot and not self._dot_native:
             # the caller's points in the working precision first (what the kernel is defined on), then the identity

@@ -48,12 +48,18 @@ namespace kmvp {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MFMA_TILE = 32;      // sources per tile = targets per wave
 constexpr int MFMA_AUG = 6;        // augmentation columns appended to the D coordinates
 constexpr int MFMA_V_STRIDE = 72;  // bytes per transposed-signal row (32 bf16 + 8 pad)
 
 __host__ __device__ constexpr int mfma_ksteps(int D) { return (D + MFMA_AUG + 15) / 16; }
+// exp(<x,y>) (K_EXPDOT): no norms; the LAST three columns of the last k-step carry the target's shift and the pad mask
+//   source j :  [ y_j (D) , 0.. , 1     , 1     , live ? 0 : -3e38 ]
+//   target i :  [ x_i (D) , 0.. , -m_hi , -m_lo , 1                ]        S[j][i] = <x_i, y_j> log2(e) - m_i
+constexpr int MFMA_DOT_AUG = 3;
+__host__ __device__ constexpr int mfma_ksteps_dot(int D) { return (D + MFMA_DOT_AUG + 15) / 16; }
 __host__ __device__ constexpr int mfma_y_stride(int KS) { return KS * 32 + 16; }  // bytes per source row
 // bytes of one tile image, rounded up to a whole number of 16-byte pieces per thread of
 // the copying workgroup (no predication in the staging loop)
@@ -73,6 +79,7 @@ struct MfmaArgs {
   int tile_blocks;
   int64_t j_offset;
   int64_t m_total;
+  float* kexp;               // exp(<x,y>): exponents of the partial sums [segments][n_pad] (sums are at the scale 2^-kexp)
 };
 
 template <int KERNEL>
@@ -83,6 +90,8 @@ __device__ __forceinline__ float mfma_kval(float s) {
     // |s| instead of max(s, 0): a free source modifier.  s < 0 only by rounding noise of the
     // bf16/fp32 distance (~1e-6), where sqrt(|s|) ~ 1e-3 is as good an answer as 0.
     return kexp2(-__builtin_amdgcn_sqrtf(__builtin_fabsf(s)));
+  } else if constexpr (KERNEL == K_EXPDOT) {
+    return kexp2(s);  // s = <x,y> log2(e) - m_i straight from the matrix pipe
   } else {
     return __builtin_amdgcn_rsqf(__builtin_fabsf(s));
   }
@@ -100,6 +109,7 @@ template <int KERNEL>
 __device__ __forceinline__ float mfma_kval_stage2(float u) {
   if constexpr (KERNEL == K_GAUSSIAN) return kexp2(-u);
   else if constexpr (KERNEL == K_ABSEXP) return kexp2(-u);
+  else if constexpr (KERNEL == K_EXPDOT) return kexp2(u);
   else return __builtin_amdgcn_rsqf(__builtin_fabsf(u));
 }
 
@@ -118,6 +128,68 @@ __device__ __forceinline__ void mfma_sched_pattern() {
 // row of the 32x32 accumulator held in register `reg` by lane half `h`
 __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * h;
+}
+
+// ---- exp(<x,y>): the per-target running shift (softmax attention without a range limit).
+// The kernel values of target i are p = 2^(s - m_i), s = <x_i, y_j> log2(e); m_i is an INTEGER that rides in the target's
+// MFMA operand (two bf16 columns: a multiple of 128 and a remainder, both exact), so a pair costs no instruction for it.
+// bf16 and fp32 share their exponent range, so m_i only has to keep the sums inside it: it is set from the row maximum of
+// the FIRST source tile a wave sees (p <= 1 there) and touched again only when a target's running denominator passes 2^64
+// -- detected for one compare per tile on the sum the denominator needs anyway, BEFORE the tile's values enter the second
+// product.  An event (wave-uniform, rare) moves m_i up by delta_i >= 0: the tile's s and the next tile's (already on their
+// way with the old operand) are lowered by delta, the denominator and the target's output rows are scaled by 2^-delta
+// (exact), the operand columns are patched.  Values more than 126 binades under a row's own maximum flush to zero.
+// Partial sums leave the kernel with their exponent (MfmaArgs::kexp = -m_i) and are merged as (mantissa, exponent) pairs.
+constexpr float MFMA_DOT_LIMIT = 1.8446744e19f;  // 2^64
+constexpr float MFMA_DOT_MAX_SHIFT = 32000.f;    // |m| < 2^15: m_hi / 128 and m_lo are bf16 integers
+
+// one target tile of one wave.  s: the tile's 16 values per lane (target = lane & 31, both lane halves), lowered in place;
+// s_next: the next source tile's, if already computed; o: the tile's output accumulators (row acc_row(q, h) = target);
+// den: this lane's partial denominator; m: the target's shift; xlast: the target's operand of the last k-step; scratch:
+// 32 floats of LDS owned by the wave.
+template <int NT>
+__device__ __forceinline__ void mfma_dot_event(bool first, f32x16& s, f32x16* s_next, f32x16 (&o)[NT], float& den, float& m,
+                                               bf16x8& xlast, float* scratch, int r, int h) {
+  float tmax = s[0];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, s[q]);
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+  float delta = ceilf(tmax);                       // the tile's largest value becomes <= 1
+  if (!first) {
+    int e = 0;
+    const float dboth = den + __shfl_xor(den, 32);
+    if (dboth > 0.f && dboth < INFINITY) (void)frexpf(dboth, &e);
+    delta = fmaxf(fmaxf(delta, (float)e), 0.f);    // ... and the running denominator <= 1; the shift only ever grows
+  }
+  if (!(delta == delta)) delta = 0.f;              // a NaN row stays NaN
+  const float m_new = fminf(fmaxf(m + delta, -MFMA_DOT_MAX_SHIFT), MFMA_DOT_MAX_SHIFT);
+  delta = m_new - m;
+  m = m_new;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s[q] -= delta;
+  if (s_next != nullptr) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) (*s_next)[q] -= delta;
+  }
+  const int di = (int)delta;
+  den = ldexpf(den, -di);
+  // the output rows are targets too, in another layout: the deltas travel through LDS
+  if (h == 0) scratch[r] = delta;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const mf32x4 f = *reinterpret_cast<const mf32x4*>(scratch + 8 * g + 4 * h);  // rows 8 g + 4 h + (0..3) = acc_row(4 g + j, h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt][4 * g + j] = ldexpf(o[nt][4 * g + j], -(int)f[j]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float m_hi = 128.f * truncf(m_new * (1.f / 128.f));
+  if (h == 1) {  // k = 16 KS - 3 and 16 KS - 2: elements 5 and 6 of the upper lane half's fragment
+    xlast[5] = (__bf16)(-m_hi);
+    xlast[6] = (__bf16)(m_hi - m_new);
+  }
 }
 
 template <int KERNEL, int KS, int NT, int TW>
@@ -172,9 +244,16 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
 
   f32x16 o[TW][NT];
   float den[TW];
+  // exp(<x,y>): the targets' shifts, whether a tile has set them yet, and the wave's LDS scratch of an event
+  constexpr bool DOT = KERNEL == K_EXPDOT;
+  __shared__ __attribute__((aligned(16))) float dscr[DOT ? WPB : 1][DOT ? MFMA_TILE : 1];
+  float msh[TW];
+  bool unset[TW];
 #pragma unroll
   for (int w = 0; w < TW; ++w) {
     den[w] = 0.f;
+    msh[w] = 0.f;
+    unset[w] = true;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -245,6 +324,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
 
       // ---- 2. kernel values on the VALU; target on the lane, 16 sources in registers
       float p[16];
+      float dsum = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float k = mfma_kval<KERNEL>(s[q]);
@@ -252,7 +332,21 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
           if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
         }
         p[q] = k;
-        den[w] += k;
+        if constexpr (DOT) dsum += k;
+        else den[w] += k;
+      }
+      if constexpr (DOT) {
+        if (unset[w] || __any(!(den[w] + dsum < MFMA_DOT_LIMIT))) {  // wave-uniform, rare after the first tile
+          mfma_dot_event<NT>(unset[w], s, nullptr, o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
+          unset[w] = false;
+          dsum = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            p[q] = mfma_kval<KERNEL>(s[q]);
+            dsum += p[q];
+          }
+        }
+        den[w] += dsum;
       }
 
       // ---- 3. O[i][e] += sum_j P[j][i] V[j][e]: P registers are the A operand
@@ -280,6 +374,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) part[(int64_t)acc_row(q, h) * (NT * 32) + nt * 32 + r] = o[w][nt][q];
     if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = dsum;
+    if constexpr (DOT) {
+      if (h == 0) a.kexp[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = unset[w] ? INFINITY : -msh[w];
+    }
   }
 }
 
@@ -316,6 +413,8 @@ template <int KERNEL, int KS, int NT, int VAR = 0>
 __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs a) {
   constexpr bool DEN_MFMA = (VAR & 1) != 0;
   constexpr bool ROTATE = (VAR & 4) != 0;
+  constexpr bool DOT = KERNEL == K_EXPDOT;
+  static_assert(!DOT || VAR == 0, "exp(<x,y>): the running shift is built into the plain pipeline only");
   static_assert((VAR & 2) == 0, "bit 1 was the deferred-P.V arm: measured 5 % slower and removed (LAB_NOTES.md)");
   constexpr int TW = 2;
   constexpr int KD = 16 * KS;
@@ -363,9 +462,14 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
   f32x16 oden[TW];  // DEN_MFMA: column 0 holds the denominators of target tile w (a tile of its own per target tile: a
                     // shared one would let a NaN row of one tile -- NaN x 0 -- into the other tile's sums)
   float den[TW];
+  __shared__ __attribute__((aligned(16))) float dscr[DOT ? WAVES_PER_BLOCK : 1][DOT ? MFMA_TILE : 1];
+  float msh[TW];
+  bool unset[TW];
 #pragma unroll
   for (int w = 0; w < TW; ++w) {
     den[w] = 0.f;
+    msh[w] = 0.f;
+    unset[w] = true;
 #pragma unroll
     for (int q = 0; q < 16; ++q) oden[w][q] = 0.f;
 #pragma unroll
@@ -535,6 +639,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
 #pragma unroll
     for (int w = 0; w < TW; ++w) {
       float p[16];
+      float dsum = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float k = mfma_kval<KERNEL>(s_cur[w][q]);
@@ -542,7 +647,8 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
           if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
         }
         p[q] = k;
-        if constexpr (!DEN_MFMA) den[w] += k;
+        if constexpr (DOT) dsum += k;
+        else if constexpr (!DEN_MFMA) den[w] += k;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -565,6 +671,25 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DOT) {
+        // (kmvp_mfma.hpp "the per-target running shift"; the distances of tile t + 1 are already on their way with the old
+        // operand: the event lowers them too)
+        if (unset[w] || __any(!(den[w] + dsum < MFMA_DOT_LIMIT))) {
+          mfma_dot_event<NT>(unset[w], s_cur[w], &s_next[w], o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
+          unset[w] = false;
+          dsum = 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            p[q] = mfma_kval<KERNEL>(s_cur[w][q]);
+            dsum += p[q];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[w][s2][j] = (__bf16)p[8 * s2 + j];
+        }
+        den[w] += dsum;
+      }
     }
     pv(TW - 1, pa[TW - 1], vb);
     buf = buf1;
@@ -604,6 +729,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
     } else {
       const float dsum = den[w] + __shfl_xor(den[w], 32);
       if (h == 0) a.partd[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = dsum;
+    }
+    if constexpr (DOT) {
+      if (h == 0) a.kexp[(int64_t)seg * a.n_pad + i0 + w * MFMA_TILE + r] = unset[w] ? INFINITY : -msh[w];
     }
   }
 }

@@ -1633,14 +1633,17 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   const int E = sig == SIG_DENSITY ? 1 : c->E;
   const int NE = sig == SIG_NORM ? E + 1 : E;
   const int64_t N = c->N, M = c->M;
-  const int KS = mfma_ksteps(D);
+  // exp(<x,y>) (include/kmvp.h kmvp_expdot, bfloat16): S = X Y^T log2(e) straight from the matrix pipe, the per-target
+  // running shift of kmvp_mfma.hpp, partial sums as (mantissa, exponent) pairs and the shifted tail
+  const bool dot = kernel == K_EXPDOT;
+  const int KS = dot ? mfma_ksteps_dot(D) : mfma_ksteps(D);
   const int NT = (E + 31) / 32;
   if (KS > MFMA_MAX_KS || NT > MFMA_MAX_NT)
-    return fail(c, KMVP_E_UNSUPPORTED, "bf16 MFMA path is instantiated for D <= 138 and E <= 128");
+    return fail(c, KMVP_E_UNSUPPORTED, "bf16 MFMA path is instantiated for D <= 138 (exp(<x,y>): 141) and E <= 128");
   const int KD = 16 * KS;
   const int NEP = NT * 32;
   const int64_t IMG = mfma_image_bytes(KS, NT);
-  const float scale = scale_for<float>(kernel);
+  const float scale = dot ? 1.2011224087864498f /* sqrt(log2 e) on both sides */ : scale_for<float>(kernel);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   // target tiles of 32 per wave ("targets_per_lane" option): 1, 2, or (default, where instantiated)
   // 2 with the software-pipelined kernel
@@ -1650,7 +1653,7 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   // rotated by one transcendental stage; the denominators stay on the VALU -- on the matrix pipe they save 2 % of the
   // cycles and nothing of the time under the power limit (profiles/r03_c3_variants.txt); the single-transcendental kernels
   // gain nothing from either
-  const int variant = c->opt_mfma_variant >= 0 ? c->opt_mfma_variant : (kernel == K_ABSEXP ? 4 : 0);
+  const int variant = dot ? 0 : (c->opt_mfma_variant >= 0 ? c->opt_mfma_variant : (kernel == K_ABSEXP ? 4 : 0));
   const int64_t tile = (int64_t)MFMA_TILE * TW * WAVES_PER_BLOCK;
   const int64_t n_pad = round_up(N, tile);
   const int64_t tile_blocks = n_pad / tile;
@@ -1671,14 +1674,14 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   if (pts_stale) {
     if ((rc = ensure(c, c->xs, (size_t)n_pad * KD * 2))) return rc;
     hipLaunchKernelGGL(pack_mfma_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream,
-                       x_raw, (__bf16*)c->xs.p, N, n_pad, D, KD, scale);
+                       x_raw, (__bf16*)c->xs.p, N, n_pad, D, KD, scale, dot ? 1 : 0);
   }
   if (sig_stale) {
     if ((rc = ensure(c, c->rec, (size_t)m_tiles * IMG))) return rc;
     hipLaunchKernelGGL(pack_mfma_sources_kernel, dim3(blocks_for(m_tiles * MFMA_TILE)), dim3(256), 0,
                        c->stream, (const float*)c->y_raw.p,
                        sig == SIG_DENSITY ? (const float*)nullptr : (const float*)c->b_raw.p,
-                       (unsigned char*)c->rec.p, M, m_tiles, D, E, KS, NT, scale);
+                       (unsigned char*)c->rec.p, M, m_tiles, D, E, KS, NT, scale, dot ? 1 : 0);
   }
   HIP_TRY(c, hipGetLastError());
   c->packed_points_ver = c->points_ver;
@@ -1702,10 +1705,17 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   a.tile_blocks = (int)tile_blocks;
   a.j_offset = c->j_offset;
   a.m_total = c->m_total;
+  a.kexp = nullptr;
+  if (dot) {
+    if ((rc = ensure(c, c->kexp, (size_t)segments * n_pad * sizeof(float)))) return rc;
+    if ((rc = ensure(c, c->kshift, (size_t)n_pad * sizeof(double)))) return rc;
+    a.kexp = (float*)c->kexp.p;
+  }
   const dim3 grid((unsigned)(tile_blocks * segments));
   HIP_TRY(c, mark(c, 0));
   hipError_t le;
   switch (kernel) {
+    case K_EXPDOT: le = launch_mfma_expdot(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
     case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
     case K_ABSEXP: le = launch_mfma_absexp(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
     default: le = launch_mfma_invdist(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
@@ -1715,6 +1725,14 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
 
   const int64_t count = (int64_t)NE * n_pad;
   if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
+  if (dot) {
+    hipLaunchKernelGGL(mfma_reduce_shifted_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
+                       (const float*)c->part.p, (const float*)c->partd.p, (const float*)c->kexp.p, (double*)c->sums.p,
+                       (double*)c->kshift.p, n_pad, NEP, E, segments, sig == SIG_NORM ? 1 : 0);
+    HIP_TRY(c, hipGetLastError());
+    c->note = "exp(<x,y>) on the bf16 matrix cores with the per-target online shift, (mantissa, exponent) partial sums";
+    return finish_product_shifted(c, N, n_pad, E, sig);
+  }
   hipLaunchKernelGGL(mfma_reduce_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
                      (const float*)c->part.p, (const float*)c->partd.p, (double*)c->sums.p, n_pad, NEP,
                      E, segments, sig == SIG_NORM ? 1 : 0);
@@ -1860,9 +1878,11 @@ int run_product(kmvp_ctx* c, int kernel, bool normalise) {
   const int sig = c->density ? SIG_DENSITY : (normalise ? SIG_NORM : SIG_PRODUCT);
   if (kernel == K_EXPDOT) {
     // k = exp(<x,y>) (include/kmvp.h kmvp_expdot): float32 on fastmm_kernel's matrix-core path only
-    if (c->dtype != KMVP_F32 || c->D > FMM_MAX_D)
-      return fail(c, KMVP_E_UNSUPPORTED, "exp(<x,y>) is built for float32 and D <= 64 (other cases: the plugin's Gaussian identity)");
     if (c->density) return fail(c, KMVP_E_UNSUPPORTED, "exp(<x,y>): pass a signal of ones for density estimation");
+    if (c->dtype == KMVP_BF16) return run_product_mfma(c, K_EXPDOT, sig);  // D <= 141, E <= 128
+    if (c->dtype != KMVP_F32 || c->D > FMM_MAX_D)
+      return fail(c, KMVP_E_UNSUPPORTED,
+                  "exp(<x,y>) is built for float32 at D <= 64 and for bfloat16 (other cases: the plugin's Gaussian identity)");
     return run_product_fastmm(c, K_GAUSSIAN, sig, true);
   }
   if (c->dtype == KMVP_BF16) return run_product_mfma(c, kernel, sig);

@@ -112,13 +112,13 @@ def test_float16_is_at_least_as_accurate_as_the_references_float16(case, expecte
 def test_exp_dot_attention_matches_direct_evaluation():
     """k(x, y) = exp(<x, y>) (README.md:51-59; PARITY UNPINNED: no reference plugin implements it) against a direct
     float64 evaluation: softmax attention (row-normalised, E value channels), plain products, densities; float32 / float16
-    at D <= 64 on the native online-max kernel (fastmm_kernel, ONLINE = 1), float64 and bfloat16 through the Gaussian identity;
+    at D <= 64 on the native online-max kernel (fastmm_kernel, ONLINE = 1), bfloat16 on mfma_pipe_kernel's, float64 through the Gaussian identity;
     targets != sources; key norms spanning |y|^2/2 up to ~60."""
     rs = np.random.RandomState(99)
     native = ("fastmm_kernel",)
     shapes = [(3, 40000, 40000, 4, "float32", 1.0, native), (16, 700, 900, 8, "float32", 1.0, native),
               (16, 700, 900, 8, np.float64, 2.5, None), (64, 1024, 2048, 64, "float32", 0.35, native),
-              (64, 1024, 2048, 64, "bfloat16", 0.35, None), (3, 500, 300, 1, "float16", 1.0, native)]
+              (64, 1024, 2048, 64, "bfloat16", 0.35, ("mfma_pipe_kernel",)), (3, 500, 300, 1, "float16", 1.0, native)]
     for D, N, M, E, precision, spread, want_kernel in shapes:
         y = rs.randn(M, D) * spread / np.sqrt(D) * (1.5 if D == 3 else 3.0)
         x = rs.randn(N, D) * spread / np.sqrt(D) * (1.5 if D == 3 else 3.0)
@@ -261,11 +261,69 @@ def test_exp_dot_native_kernel_has_no_range_limit():
             assert big.any() and not np.isfinite(got[big]).any()
     # the identity route says so instead of zeroing small-norm sources
     with pytest.raises(NotImplementedError, match="spans"):
-        algo = MI355XProduct(kernel="exp-dot", dimension=8, normalize_rows=True, precision="bfloat16")
+        algo = MI355XProduct(kernel="exp-dot", dimension=70, normalize_rows=True, precision="float32")  # D > 64: identity
         try:
-            algo.prepare_data(source_points=rs.randn(100, 8) * 6.0, target_points=rs.randn(10, 8), same_points=False)
+            algo.prepare_data(source_points=rs.randn(100, 70) * 2.0, target_points=rs.randn(10, 70), same_points=False)
         finally:
             algo.done()
+
+
+def bf16_round(a):
+    """float64 -> the nearest bfloat16 (ties to even), as float64: what the packing kernels make of float32 inputs."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return u.view(np.float32).astype(np.float64)
+
+
+def test_exp_dot_bfloat16_native_kernel_with_online_shift():
+    """bfloat16 exp(<x, y>) on mfma_pipe_kernel / mfma_kernel with the per-target running shift (kmvp_mfma.hpp): softmax
+    attention and plain products against the direct float64 evaluation (PARITY UNPINNED, as every exp-dot check), on logits
+    far outside what the Gaussian identity could take (|y|^2/2 spread in the hundreds, logits from -2000 to +2000), with
+    the largest logits arriving LATE in the source order (the shift has to move while sums are under way), several source
+    segments, ragged sizes, E beyond one column tile, and a signal of ones.  The yardstick is the bf16 tolerance of this
+    file on inputs pre-rounded to what the kernel sees (the operands are x, y times sqrt(log2 e) rounded to bf16: a logit
+    carries ~2^-9 |x||y| / sqrt(D) of that rounding, so wide-logit rows are compared with their logits' own uncertainty)."""
+    rs = np.random.RandomState(515)
+    seen = set()
+    for D, N, M, E, scale, late in ((64, 1000, 4096, 64, 0.35, False), (64, 777, 5000, 64, 1.0, True), (16, 300, 2050, 8, 12.0, True),
+                                    (100, 200, 1500, 96, 0.6, False), (8, 64, 33, 1, 6.0, True), (64, 4096, 65536, 16, 0.5, True)):
+        y = rs.randn(M, D) * scale
+        x = rs.randn(N, D) * scale
+        if late:  # sources sorted by norm: the big logits come last
+            y = y[np.argsort((y * y).sum(axis=1))]
+        b = rs.randn(M, E)
+        for norm in (True, False):
+            algo = MI355XProduct(kernel="exp-dot", dimension=D, normalize_rows=norm, precision="bfloat16")
+            try:
+                algo.prepare_data(source_points=y, target_points=x, same_points=False)
+                algo.fit()
+                algo.prepare_query(source_signal=b)
+                algo.query()
+                got = algo.get_result()
+                seen.add(algo.device_kernel)
+                note = algo.get_additional().get("dispatch_note", "")
+            finally:
+                algo.done()
+            assert "online shift" in note, note
+            rows = rs.choice(N, size=min(N, 200), replace=False)
+            # the truth on the operands the kernel multiplies: (x c) and (y c) rounded to bf16, c = sqrt(log2 e)
+            c = 1.2011224087864498
+            xr, yr = bf16_round(x[rows] * c) / c, bf16_round(y * c) / c
+            with np.errstate(over="ignore", invalid="ignore"):
+                want = kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr, source_signal=b, normalize_rows=norm)
+                mass = want if norm else kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr, source_signal=np.abs(b))
+            live = np.isfinite(want).all(axis=1) & np.isfinite(mass).all(axis=1)
+            if norm:
+                assert live.all(), (D, scale)  # softmax rows exist whatever the logits
+            elif not live.any():
+                continue  # every plain product of this shape leaves float64
+            assert np.isfinite(got[rows][live]).all(), (D, N, M, E, norm)
+            yard = np.abs(want[live]).max() if norm else np.abs(mass[live])
+            err = float((np.abs(got[rows][live] - want[live]) / yard).max())
+            assert err <= TOL_BF16, (D, N, M, E, scale, norm, err)
+            if norm:
+                assert got.min() >= b.min() - 1e-2 and got.max() <= b.max() + 1e-2
+    assert seen == {"mfma_pipe_kernel", "mfma_kernel"}, seen
 
 
 def test_targets_far_from_every_source_keep_float32_accuracy():
