@@ -74,8 +74,8 @@ def main():
     y, x, b = f32(rs.randn(3001, 8) * 3.5), f32(rs.randn(500, 8)), f32(rs.randn(3001, 3))
     # (sources ordered by norm: the ranks' exponents then differ by hundreds)
     y = y[np.argsort(np.sum(y * y, axis=1))]
-    for normalize in (True, False):
-        algo = MI355XProduct(kernel="exp-dot", dimension=8, normalize_rows=normalize, precision="float32", device=0, comm=comm)
+    for normalize, precision in ((True, "float32"), (False, "float32"), (True, "bfloat16"), (False, "bfloat16")):
+        algo = MI355XProduct(kernel="exp-dot", dimension=8, normalize_rows=normalize, precision=precision, device=0, comm=comm)
         try:
             algo.prepare_data(source_points=y, target_points=x, same_points=False)
             algo.fit()
@@ -85,12 +85,24 @@ def main():
             meta = algo.get_additional()
         finally:
             algo.done()
-        want = kmvp_oracle.exp_dot_product(source_points=y, target_points=x, source_signal=b, normalize_rows=normalize)
-        scale = np.max(np.abs(want), axis=1, keepdims=True)
+        ys, xs = y, x
+        if precision == "bfloat16":  # the truth on the operands the kernel multiplies (points x sqrt(log2 e), rounded to bf16)
+            c = 1.2011224087864498
+
+            def bf16(a):
+                u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+                return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64)
+
+            ys, xs = bf16(y * c) / c, bf16(x * c) / c
+        want = kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=b, normalize_rows=normalize)
+        mass = want if normalize else kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=np.abs(b))
+        scale = np.max(np.abs(mass), axis=1, keepdims=True)
         e = float(np.max(np.abs(got - want) / scale))
-        assert meta["device_kernel"] == "fastmm_kernel" and "online shift" in meta["dispatch_note"] and meta["rccl_ranks"] == world, meta
-        assert np.isfinite(got).all() and e <= 1e-4, ("exp-dot", normalize, e)
-        report.append({"kernel": "exp-dot", "normalize": normalize, "rel_err": e, "device_kernel": meta["device_kernel"]})
+        native = "fastmm_kernel" if precision == "float32" else "mfma_pipe_kernel"
+        assert meta["device_kernel"] == native and "online shift" in meta["dispatch_note"] and meta["rccl_ranks"] == world, meta
+        assert np.isfinite(got).all() and e <= (1e-4 if precision == "float32" else 1e-2), ("exp-dot", precision, normalize, e)
+        report.append({"kernel": "exp-dot", "precision": precision, "normalize": normalize, "rel_err": e,
+                       "device_kernel": meta["device_kernel"]})
 
     # sharded solvers: replicated Krylov vectors, operator summed over the ranks in every iteration
     for kernel, n, rtol in (("gaussian", 3000, 1e-6), ("inverse-distance", 1500, 1e-8)):
