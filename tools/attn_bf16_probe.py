@@ -16,7 +16,10 @@ rs = np.random.RandomState(n + D)
 y = rs.rand(n, D) / np.sqrt(D)
 b = rs.randn(n, E)
 rows = np.sort(rs.choice(n, size=128, replace=False))
-for kernel, pts in (("absolute-exponential", y), ("gaussian", y), ("exp-dot", (rs.randn(n, D) * 0.35)), ("exp-dot", rs.randn(n, D))):
+# (the last line: exp<x, y> on the SAME narrow cloud as the first two -- the launches are power-limited and the operand bits
+# of nearly equal weights toggle less than those of a real softmax)
+for kernel, pts in (("absolute-exponential", y), ("gaussian", y), ("exp-dot", (rs.randn(n, D) * 0.35)), ("exp-dot", rs.randn(n, D)),
+                    ("exp-dot", y)):
     algo = MI355XProduct(kernel=kernel, dimension=D, normalize_rows=True, precision="bfloat16")
     try:
         algo.prepare_data(source_points=pts, target_points=pts, same_points=True)
