@@ -1,0 +1,106 @@
+// Micro-benchmark for mfma_pipe_kernel's trip at config 3 ("v_mfma_f32_16x16x32_bf16 tiles" as a measured
+// arm before anybody rewrites the kernel).  Per 32 sources x 32 targets, D = E = 64, a wave issues
+//   32x32x16 shape:   5 distance MFMAs + 4 P.V MFMAs                           =  9 MFMAs (288 pipe cycles)
+//   16x16x32 shape:   4 output tiles x 3 k-steps (K = 70 -> 96) + 2 x 4 P.V    = 20 MFMAs (320 pipe cycles)
+// and the same VALU work: 32 transcendentals (sqrt + exp2 per value), 16 adds, 8 packed conversions.  Operands and values
+// are random (the launches are power-limited: zero data would flatter both).  Two waves per SIMD, free-running; the VALU
+// block and the MFMA block alternate as in the real loop (the MFMAs of a trip read operands converted in the trip before).
+// Build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 -o mfma_c3_trip mfma_c3_trip.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// 16 values: sqrt, exp2, add into a running sum, convert pairwise to bf16 (two 8-element fragments)
+__device__ __forceinline__ void values(float (&v)[16], float& den, bf16x8 (&pa)[2], int trans) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float u = v[q];
+    if (trans >= 2) u = __builtin_amdgcn_sqrtf(__builtin_fabsf(u));
+    if (trans >= 1) u = __builtin_amdgcn_exp2f(-u);
+    den += u;
+    pa[q >> 3][q & 7] = (__bf16)u;
+    v[q] = u + 0.37f;  // keeps the chain data-dependent and in range
+  }
+}
+
+template <int SHAPE, int TRANS, int MFMA_ON>
+__global__ void __launch_bounds__(256) trip(float* out, int iters, unsigned seed) {
+  unsigned s = seed + threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+  auto next = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) / 65536.f - 0.5f; };
+  bf16x8 ya[5], xb[5], vb[4], pa[2];
+  for (int t = 0; t < 5; ++t) for (int j = 0; j < 8; ++j) { ya[t][j] = (__bf16)next(); xb[t][j] = (__bf16)next(); }
+  for (int t = 0; t < 4; ++t) for (int j = 0; j < 8; ++j) vb[t][j] = (__bf16)next();
+  for (int t = 0; t < 2; ++t) for (int j = 0; j < 8; ++j) pa[t][j] = (__bf16)next();
+  float v[16], den = 0.f;
+  for (int q = 0; q < 16; ++q) v[q] = 1.0f + next();
+  f32x16 o32[2], s32;
+  f32x4v o16[8], s16[4];
+  for (int t = 0; t < 2; ++t) for (int j = 0; j < 16; ++j) o32[t][j] = 0.f;
+  for (int j = 0; j < 16; ++j) s32[j] = 0.f;
+  for (int t = 0; t < 8; ++t) for (int j = 0; j < 4; ++j) o16[t][j] = 0.f;
+  for (int t = 0; t < 4; ++t) for (int j = 0; j < 4; ++j) s16[t][j] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+    values(v, den, pa, TRANS);
+    __builtin_amdgcn_sched_barrier(0);
+    if (MFMA_ON) {
+      if (SHAPE == 32) {
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) s32 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[ks], xb[ks], s32, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o32[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[m >> 1], vb[m], o32[m & 1], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) s16[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ya[ks + (t & 1)], xb[ks + (t >> 1)], s16[t], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) o16[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[m & 1], vb[m & 3], o16[m], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // feed a little of the distance tile back so that it is not dead code, as the real loop consumes it
+    if (SHAPE == 32) v[it & 15] += s32[it & 15] * 1e-30f;
+    else v[it & 15] += s16[it & 3][(it >> 2) & 3] * 1e-30f;
+  }
+  float r = den;
+  for (int q = 0; q < 16; ++q) r += v[q];
+  for (int t = 0; t < 2; ++t) for (int j = 0; j < 16; ++j) r += o32[t][j];
+  for (int t = 0; t < 8; ++t) for (int j = 0; j < 4; ++j) r += o16[t][j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int SHAPE, int TRANS, int MFMA_ON>
+int run(const char* name) {
+  float* out;
+  const int blocks = 512, iters = 10000;  // two 256-thread workgroups per CU: two waves per SIMD
+  CHECK(hipMalloc(&out, sizeof(float) * 512 * 256));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((trip<SHAPE, TRANS, MFMA_ON>), dim3(blocks), dim3(256), 0, 0, out, iters, 777u);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL((trip<SHAPE, TRANS, MFMA_ON>), dim3(blocks), dim3(256), 0, 0, out, iters, 777u);
+  CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+  float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 5;
+  // a SIMD runs 2 waves x iters trips; a trip stands for 1024 pairs x 258 flop of config 3
+  printf("%-72s %8.3f ms  %7.1f nominal cycles per SIMD per trip   (config-3 equivalent %5.0f TFLOP/s)\n", name, ms,
+         ms * 1e-3 * 2.4e9 / (2.0 * iters), MFMA_ON ? 2.0 * iters * 1024 * 1024.0 * 258.0 / (ms * 1e-3) / 1e12 : 0.0);
+  CHECK(hipFree(out));
+  return 0;
+}
+
+int main() {
+  if (run<32, 2, 1>("9 x 32x32x16 + sqrt/exp2/add/cvt of 16 values   (exp(-r), today)")) return 1;
+  if (run<16, 2, 1>("20 x 16x16x32 + the same VALU work")) return 1;
+  if (run<32, 1, 1>("9 x 32x32x16 + exp2/add/cvt                     (Gaussian, softmax)")) return 1;
+  if (run<16, 1, 1>("20 x 16x16x32 + exp2/add/cvt")) return 1;
+  if (run<32, 2, 0>("VALU work alone (sqrt + exp2)")) return 1;
+  if (run<32, 1, 0>("VALU work alone (exp2)")) return 1;
+  if (run<32, 0, 1>("9 x 32x32x16 + add/cvt only")) return 1;
+  if (run<16, 0, 1>("20 x 16x16x32 + add/cvt only")) return 1;
+  if (run<32, 2, 1>("9 x 32x32x16 + sqrt/exp2/add/cvt (again)")) return 1;
+  return 0;
+}
