@@ -326,6 +326,61 @@ def test_exp_dot_bfloat16_native_kernel_with_online_shift():
     assert seen == {"mfma_pipe_kernel", "mfma_kernel"}, seen
 
 
+def test_exp_dot_bfloat16_edge_cases():
+    """The bf16 exp(<x, y>) kernels at their edges: one source / one target, targets == sources, density estimation (the
+    plugin passes a signal of ones), the widest instantiated shape (D = 141, E = 128: mfma_kernel), a D beyond it (refused,
+    not mis-served), and non-finite coordinates: a NaN target poisons its own row only, every other row stays right."""
+    rs = np.random.RandomState(616)
+    c = 1.2011224087864498
+
+    def run(y, x, b, norm, same=False, dens=False):
+        algo = MI355XProduct(kernel="exp-dot", dimension=y.shape[1], normalize_rows=norm, precision="bfloat16")
+        try:
+            algo.prepare_data(source_points=y, target_points=y if same else x, same_points=same, density_estimation=dens)
+            algo.fit()
+            algo.prepare_query(source_signal=b)
+            algo.query()
+            return algo.get_result(), algo.device_kernel
+        finally:
+            algo.done()
+
+    def truth(y, x, b, norm):
+        yr, xr = bf16_round(y * c) / c, bf16_round(x * c) / c
+        want = kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr, source_signal=b, normalize_rows=norm)
+        mass = want if norm else kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr,
+                                                              source_signal=None if b is None else np.abs(b))
+        return want, mass
+
+    for D, N, M, E in ((8, 1, 1, 1), (8, 70, 1, 3), (8, 1, 70, 3), (5, 33, 257, 2), (141, 100, 300, 128)):
+        y, x, b = rs.randn(M, D) * 0.5, rs.randn(N, D) * 0.5, rs.randn(M, E)
+        for norm in (True, False):
+            got, kname = run(y, x, b, norm)
+            want, mass = truth(y, x, b, norm)
+            yard = np.abs(want).max() if norm else np.abs(mass)
+            assert got.shape == (N, E) and float((np.abs(got - want) / yard).max()) <= TOL_BF16, (D, N, M, E, norm, kname)
+    # targets == sources; density (a = sum_j k: the reference's density_estimation branch, bruteforce.py:146-149)
+    y = rs.randn(500, 16) * 0.7
+    got, _ = run(y, None, rs.randn(500, 2), True, same=True)
+    assert np.isfinite(got).all()
+    got, _ = run(y, None, None, False, same=True, dens=True)
+    want, _ = truth(y, y, None, False)
+    assert got.shape == (500, 1) and float((np.abs(got - want) / np.abs(want)).max()) <= TOL_BF16
+    # beyond the widest instantiation: an error, never another kernel's answer
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        run(rs.randn(50, 150), rs.randn(20, 150), rs.randn(50, 1), True)
+    # non-finite coordinates
+    y, x, b = rs.randn(300, 8), rs.randn(64, 8), rs.randn(300, 2)
+    x[5, 3] = np.nan
+    for norm in (True, False):
+        got, _ = run(y, x, b, norm)
+        ok = np.ones(64, dtype=bool)
+        ok[5] = False
+        want, mass = truth(y, x[ok], b, norm)
+        yard = np.abs(want).max() if norm else np.abs(mass)
+        assert np.isnan(got[5]).all()
+        assert float((np.abs(got[ok] - want) / yard).max()) <= TOL_BF16, norm
+
+
 def test_targets_far_from_every_source_keep_float32_accuracy():
     """the matrix-core forms with several signal columns store a kernel value as 2^15 k in two f16
     pieces.  With ONE global shift a target 4-5 away from every source had its whole row at or below the f16 floor (5e-2
