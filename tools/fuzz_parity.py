@@ -36,7 +36,7 @@ def one_case(rs):
     offset = 0.0 if same else float(rs.choice([0.0, 0.0, 0.0, 2.0, 4.0, 7.0]))
     if rs.rand() < 0.12:  # exp<x, y>: the online-max kernel (float32, D <= 64) or the Gaussian identity
         kernel, form, tiles, dens = "exp-dot", None, 0, False
-        precision = ["float32", "float32", "float64"][rs.randint(3)]
+        precision = ["float32", "float32", "float64", "bfloat16"][rs.randint(4)]
     return dict(kernel=kernel, D=D, E=E, N=N, M=M, same=same, norm=norm, dens=dens, precision=precision, form=form,
                 tiles=tiles, spread=spread, offset=offset)
 
@@ -150,6 +150,11 @@ def run_case(c, rs):
     tol = 1e-11 if c["precision"] == "float64" else 2e-5
     if c["kernel"] == "inverse-distance" and c["precision"] != "float64":
         tol = 2e-4  # 1/r of nearly coincident points
+    if c["offset"] > 0 and c["precision"] != "float64" and c["kernel"] != "inverse-distance":
+        # (normalised rows of displaced targets: float32 rounds s itself, an absolute error of the exponent, as above)
+        xt = x if rows is None else x[rows]
+        smax = float(((np.maximum(xt.max(axis=0), y.max(axis=0)) - np.minimum(xt.min(axis=0), y.min(axis=0))) ** 2).sum())
+        tol += 3e-7 * (smax if c["kernel"] == "gaussian" else np.sqrt(smax))
     if forced_expanded and scale > 0:
         tol = max(tol, 2.0 * float(np.abs(ref_fast[finite].astype(np.float64) - want[finite]).max() / scale))
     if err > tol and c["precision"] != "float64" and scale > 0:
@@ -168,6 +173,14 @@ def check_exp_dot(c, got, y, x, b, rows):
     xt = y if x is None else x
     if rows is not None:
         xt = xt[rows]
+    if c["precision"] == "bfloat16":  # the truth on the operands the kernel multiplies: points x sqrt(log2 e), rounded to bf16
+        k = 1.2011224087864498
+
+        def bf16(a):
+            u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+            return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64)
+
+        y, xt = bf16(y * k) / k, bf16(xt * k) / k
     with np.errstate(over="ignore", invalid="ignore"):
         want = kmvp_oracle.exp_dot_product(source_points=y, target_points=xt, source_signal=b, normalize_rows=c["norm"])
         mass = want if c["norm"] else kmvp_oracle.exp_dot_product(source_points=y, target_points=xt, source_signal=np.abs(b))
@@ -185,6 +198,8 @@ def check_exp_dot(c, got, y, x, b, rows):
     # float32: a logit carries ~1e-7 of the largest |x| |y| as ABSOLUTE error, which is a relative error of the weight
     lmax = float(np.sqrt((xt * xt).sum(axis=1).max() * (y * y).sum(axis=1).max()))
     tol = 1e-10 * max(1.0, lmax) if c["precision"] == "float64" else 2e-5 + 5e-7 * lmax
+    if c["precision"] == "bfloat16":
+        tol = 1e-2 + 5e-7 * lmax  # bf16 kernel values in the second product
     return None if rel <= tol else f"exp-dot error {rel:.3e} > {tol:.0e}"
 
 
