@@ -65,7 +65,8 @@ KERNELS = {"gaussian": "gaussian", "absexp": "absolute-exponential", "invdist": 
 FULL_SIZE = {"2": 1000000, "3": 65536, "4": 10000000, "4shard": 10000000, "5": 100000, "attn": 100000, "softmax": 65536}
 
 # Algorithmic work per pair of each pair-loop kernel, on the unit that bounds it.
-#   cellmm_kernel: one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs -> 2 x 16 = 32 matrix flop per pair
+#   cellmm_kernel: one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs -> 2 x 16 = 32 matrix flop per pair (cellmm16_kernel: the
+#                  same on v_mfma_f32_16x16x32_f16, one per 32 sources x 16 targets)
 #   cell_kernel:   the same MFMA (bf16) for the polynomial + ONE VALU fma per pair; the VALU is the busy unit
 #   fast / cfast:  squared distance on the matrix cores, transcendental + fma per pair on the VALU
 #   lowd_kernel:   SURVEY 8d's count, 3 D + 2 E + 1 = 12 flop per pair (fma = 2, exp = 1), all VALU
@@ -76,6 +77,10 @@ ROOF = {
                       "32 matrix flop per pair (one 32x32x16 f16 MFMA per 1024 pairs: polynomial remainder of the "
                       "range-reduced exponential, weights and the sum over the sources in the accumulator) vs the dense "
                       "f16 MFMA peak 2.5 PFLOP/s at 2.4 GHz"),
+    "cellmm16_kernel": ("mfma", 32.0, PEAK_F16_MFMA_TFLOPS,
+                        "32 matrix flop per pair (one 16x16x32 f16 MFMA per 512 pairs -- two groups of 16 sources x 16 monomial "
+                        "slots against 16 targets: polynomial remainder of the range-reduced exponential, weights and the sum "
+                        "over the sources in the accumulator) vs the dense f16 MFMA peak 2.5 PFLOP/s at 2.4 GHz"),
     "cell_kernel": ("valu", 2.0, PEAK_FP32_VECTOR_TFLOPS,
                     "2 VALU flop per pair (the one fma left after the bf16 MFMA delivers the polynomial) vs the "
                     "packed-fp32 vector peak 157.3 TFLOP/s; v_fma_f32 (not packed) sustains 147 TFLOP/s here"),
@@ -96,6 +101,9 @@ KERNEL_FORM = {
     "cellmm_kernel": "cells: exp() range-reduced by grid cells; polynomial remainder, source weights and the "
                      "sum over the sources in ONE 32x32x16 f16 MFMA per 1024 pairs (fp32 accumulator carried "
                      "over a source cell)",
+    "cellmm16_kernel": "cells: exp() range-reduced by grid cells; polynomial remainder, source weights and the "
+                       "sum over the sources in ONE 16x16x32 f16 MFMA per 512 pairs (cellmm_kernel's algebra on the MFMA shape "
+                       "that sustains more under the power limit; fp32 accumulator carried over a source cell)",
     "cell_kernel": "cells: exp() range-reduced by grid cells, remainder polynomial from one bf16 MFMA per "
                    "1024 pairs, one VALU fma per pair",
     "fast_kernel": "expanded |x|^2+|y|^2-2x.y on the bf16 matrix cores, 3-way split fp32 operands "
@@ -319,7 +327,8 @@ def head_commit(path):
 
 def traffic_from_profile(kname, tag):
     """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary of this kernel on this workload."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_{kname}_traffic.json")))
+    # (the committed summaries of the headline kernel carry cellmm_kernel in their file names for both MFMA shapes)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_{'cellmm_kernel' if kname == 'cellmm16_kernel' else kname}_traffic.json")))
     if not files:
         return None, None
     rel = os.path.relpath(files[-1], ROOT)
@@ -571,13 +580,13 @@ def roofline_of(W, kname, k_ms, world=1):
         "flops_per_pair": fpp,
         "algorithmic_hbm_bytes": esize * (n * D + my_sources * (D + E) + n * E),
     }
-    if bound == "mfma" and kname == "cellmm_kernel":
+    if bound == "mfma" and kname in ("cellmm_kernel", "cellmm16_kernel"):
         r["sustained_peak_random_data"] = SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS
         r["frac_of_sustained"] = achieved / SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS
         r["sustained_note"] = ("tools/mfma_stream.hip on this pool: the same MFMA sustains 2.48 PFLOP/s on zero operands "
                                "but 1.50-1.61 PFLOP/s on random f16 operands (power limit, clock ~2.0 GHz): "
                                "profiles/r02_micro_mfma_stream.txt")
-    if kname in ("cellmm_kernel", "cell_kernel", "fast_kernel", "cfast_kernel") and cfg in ("2", "4", "4shard"):
+    if kname in ("cellmm_kernel", "cellmm16_kernel", "cell_kernel", "fast_kernel", "cfast_kernel") and cfg in ("2", "4", "4shard"):
         # SURVEY 8d's VALU model (12 flop per pair against the fp32 vector peak) does not describe kernels whose
         # exponential / squared distance runs on the matrix pipe; reported as an equivalent only
         r["survey_equivalent_tflops"] = 12.0 * shard_pairs / (k_ms * 1e-3) / 1e12
@@ -760,7 +769,7 @@ def main(argv=None):
 
     # the other forms on the same resident data, for the record (config 2, one GPU, untimed region)
     others = {}
-    if cfg == "2" and args.sqdists == "auto" and world == 1 and kname in ("cellmm_kernel", "cell_kernel", "fast_kernel"):
+    if cfg == "2" and args.sqdists == "auto" and world == 1 and kname in ("cellmm_kernel", "cellmm16_kernel", "cell_kernel", "fast_kernel"):
         algo = W.algo
 
         def side_run(code):
@@ -775,7 +784,7 @@ def main(argv=None):
 
         others["difference_form"] = side_run(0)
         others["expanded_form"] = side_run(1)
-        if kname == "cellmm_kernel":
+        if kname in ("cellmm_kernel", "cellmm16_kernel"):
             others["cell_form_valu_sum"] = side_run(4)
         algo.set_query_arguments(fast_sqdists=-1)
 

@@ -5,7 +5,7 @@
 namespace kmvp {
 
 hipError_t launch_cellmm_gaussian(int TT, int shape, const CellmmArgs& args, dim3 grid, hipStream_t stream, const char** kernel_name) {
-  if (kernel_name) *kernel_name = "cellmm_kernel";  // (both MFMA shapes: the dispatch note and the profiler tell them apart)
+  if (kernel_name) *kernel_name = shape == 1 ? "cellmm16_kernel" : "cellmm_kernel";  // the names the profiler shows
   if (shape == 1) {
     switch (TT) {
       case 1: hipLaunchKernelGGL((cellmm16_kernel<1>), grid, dim3(BLOCK_THREADS), 0, stream, args); break;

@@ -1573,7 +1573,7 @@ def test_config2_cell_kernel_on_all_rows_against_the_float64_difference_form():
         algo.fit()
         algo.prepare_query(source_signal=b)
         algo.query()
-        assert algo.device_kernel == "cellmm_kernel"  # what auto picks at the headline shape
+        assert algo.device_kernel == "cellmm16_kernel"  # what auto picks at the headline shape (the 16x16x32 form of cellmm_kernel)
         cells = algo.get_result()
         algo.set_query_arguments(fast_sqdists=4)
         algo.query()
@@ -1667,7 +1667,7 @@ def test_cellmm_kernel_both_mfma_shapes():
                         algo.prepare_query(source_signal=b)
                         algo.query()
                         outs.append(algo.get_result())
-                        assert algo.device_kernel == "cellmm_kernel"
+                        assert algo.device_kernel == ("cellmm16_kernel" if shape else "cellmm_kernel")
                     finally:
                         algo.done()
                     assert rel_err(outs[-1][::97][: len(want)], want) <= TOL32, (name, tiles, shape, norm, dens)
@@ -1895,7 +1895,7 @@ def test_runner_drives_the_headline_dataset_under_its_reference_name(tmp_path):
     assert np.max(np.abs(truth[rows] - want)) / np.max(np.abs(want)) <= TOL64
     a32, r32 = by_name["MI355XProduct(float32)"]
     a64, r64 = by_name["MI355XProduct(float64)"]
-    assert a32["device_kernel"] == "cellmm_kernel" and a64["device_kernel"] == "cell64_kernel"
+    assert a32["device_kernel"] == "cellmm16_kernel" and a64["device_kernel"] == "cell64_kernel"
     assert metrics.relative_max_error(r32, truth) <= TOL32 and metrics.relative_max_error(r64, truth) <= TOL64
     assert a32["query_time"] < 0.2 and a32["build_time"] < 0.2 and a32["run_count"] == 2
 
