@@ -59,6 +59,7 @@ PEAK_FP64_VECTOR_TFLOPS = 78.6
 PEAK_HBM_GBPS = 8000.0
 # measured on MI355X boxes of this pool (profiles/r02_micro_*.txt), for context next to the data-sheet peaks
 SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS = 1570.0   # tools/mfma_stream.hip: 1.50-1.61 PFLOP/s on random f16 operands
+SUSTAINED_F16_MFMA16_RANDOM_DATA_TFLOPS = 1735.0  # the 16x16x32 shape, two waves per SIMD (profiles/r03_micro_mfma_stream_16x16x32.txt)
 NONPACKED_FP32_FMA_TFLOPS = 147.4                # tools/valu_peak.hip: 7.37e13 v_fma_f32 lane-ops/s x 2
 
 KERNELS = {"gaussian": "gaussian", "absexp": "absolute-exponential", "invdist": "inverse-distance"}
@@ -581,11 +582,13 @@ def roofline_of(W, kname, k_ms, world=1):
         "algorithmic_hbm_bytes": esize * (n * D + my_sources * (D + E) + n * E),
     }
     if bound == "mfma" and kname in ("cellmm_kernel", "cellmm16_kernel"):
-        r["sustained_peak_random_data"] = SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS
-        r["frac_of_sustained"] = achieved / SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS
+        sustained = SUSTAINED_F16_MFMA16_RANDOM_DATA_TFLOPS if kname == "cellmm16_kernel" else SUSTAINED_F16_MFMA_RANDOM_DATA_TFLOPS
+        r["sustained_peak_random_data"] = sustained
+        r["frac_of_sustained"] = achieved / sustained
         r["sustained_note"] = ("tools/mfma_stream.hip on this pool: the same MFMA sustains 2.48 PFLOP/s on zero operands "
-                               "but 1.50-1.61 PFLOP/s on random f16 operands (power limit, clock ~2.0 GHz): "
-                               "profiles/r02_micro_mfma_stream.txt")
+                               "but 1.50-1.61 PFLOP/s on random f16 operands (power limit, clock ~2.0 GHz), the 16x16x32 "
+                               "shape 1.74 PFLOP/s at two waves per SIMD: profiles/r02_micro_mfma_stream.txt, "
+                               "profiles/r03_micro_mfma_stream_16x16x32.txt")
     if kname in ("cellmm_kernel", "cellmm16_kernel", "cell_kernel", "fast_kernel", "cfast_kernel") and cfg in ("2", "4", "4shard"):
         # SURVEY 8d's VALU model (12 flop per pair against the fp32 vector peak) does not describe kernels whose
         # exponential / squared distance runs on the matrix pipe; reported as an equivalent only
