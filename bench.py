@@ -17,10 +17,12 @@
   5       Gaussian solver K b = a, N = M = 1e5, D = 3, float64, CG with the HIP matvec as operator, to a
           relative residual of 1e-6.  One step = one solve; pairs = (iterations + 1 products) x N^2.
 
+  2shard  what one of eight ranks computes of config 2 (strong scaling at 8 GPUs), on one GPU: the plugin as rank 4 of 8
+          with a rehearsal exchange that adds nothing.  Perfect scaling would be config 2's time / 8.
   softmax (not a BASELINE config) softmax attention exp(<x,y>) (README.md:51-59), row-normalised, x = y ~ N(0,1)^64,
           N = M = 65536, E = 64, bf16 MFMA tiles with the per-target online shift (kmvp_mfma.hpp).
 
-The default run (config 2, one GPU) also measures configs 3, softmax, 4shard, 5 and the D = 3 attention shape in the same
+The default run (config 2, one GPU) also measures configs 2shard, 3, softmax, 4shard, 5 and the D = 3 attention shape in the same
 process AFTER the timed region of the headline line, a few steps each, and appends them as ``other_configs``
 (``--no-other-configs`` skips that).
 
@@ -63,7 +65,8 @@ SUSTAINED_F16_MFMA16_RANDOM_DATA_TFLOPS = 1735.0  # the 16x16x32 shape, two wave
 NONPACKED_FP32_FMA_TFLOPS = 147.4                # tools/valu_peak.hip: 7.37e13 v_fma_f32 lane-ops/s x 2
 
 KERNELS = {"gaussian": "gaussian", "absexp": "absolute-exponential", "invdist": "inverse-distance"}
-FULL_SIZE = {"2": 1000000, "3": 65536, "4": 10000000, "4shard": 10000000, "5": 100000, "attn": 100000, "softmax": 65536}
+FULL_SIZE = {"2": 1000000, "2shard": 1000000, "3": 65536, "4": 10000000, "4shard": 10000000, "5": 100000, "attn": 100000,
+             "softmax": 65536}
 
 # Algorithmic work per pair of each pair-loop kernel, on the unit that bounds it.
 #   cellmm_kernel: one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs -> 2 x 16 = 32 matrix flop per pair (cellmm16_kernel: the
@@ -123,7 +126,7 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None, help="default: 10 (config 2, 3), 3 (4shard), 2 (4, 5)")
     p.add_argument("--warmup", type=int, default=None, help="default: 2 (config 2), 50 (the millisecond launches of 3, attn), 1 otherwise")
-    p.add_argument("--config", choices=["2", "3", "4", "4shard", "5", "attn", "softmax"], default="2",
+    p.add_argument("--config", choices=["2", "2shard", "3", "4", "4shard", "5", "attn", "softmax"], default="2",
                    help="BASELINE config; attn (not a BASELINE config): D = 3 Gaussian attention with 16 value channels at "
                         "N = M = 1e5, VERDICT r1 item 9")
     p.add_argument("--points", dest="n", type=float, default=None, help="override N = M of the config (not a BASELINE run)")
@@ -357,7 +360,7 @@ class Workload:
         self.solver = False
         self.shard = None
         self.algo = None
-        if cfg == "2":
+        if cfg in ("2", "2shard"):
             self.kernel = KERNELS[kernel_arg or "gaussian"]
             self.precision = precision_arg or "float32"
         elif cfg == "3":
@@ -418,11 +421,20 @@ class Workload:
             self.algo.prepare_query(target_signal=self.a_rhs)
             self.device = device
         else:
+            if cfg == "2shard":
+                # what ONE of eight ranks computes of config 2, on one GPU: the plugin as rank 4 of 8 with a rehearsal exchange
+                # that adds nothing (the other ranks' sums are absent) -- kernel choice, cell-wise sharding, canonical exchange
+                # layout and the staging of the sums are the real ones, the all-reduce over xGMI is not there
+                from kernel_matrix_benchmarks_amd import sharding
+
+                comm = sharding.Communicator(4, 8, lambda payload: payload, host_allreduce=lambda arr, op: None)
             self.algo = MI355XProduct(kernel=self.kernel, dimension=D, normalize_rows=self.normalize, precision=self.precision,
                                       device=device, comm=comm, fast_sqdists=fast)
             self.algo.prepare_data(source_points=y, target_points=y, same_points=True)  # H2D, untimed (runner.py:75-80)
             self.algo.fit()  # cell order and tile lists (the harness books it as build_time; not part of a step)
             self.algo.prepare_query(source_signal=b)
+            if cfg == "2shard":
+                self.pairs = float(n) * float(self.algo.shard[1] - self.algo.shard[0])
 
     def step(self):
         if self.cfg == "4shard":
@@ -434,7 +446,7 @@ class Workload:
         return self.algo.device_kernel_ms, self.algo.device_total_ms
 
     def allreduce_ms(self):
-        return 0.0 if self.solver or self.cfg == "4shard" else self.algo._ctx.last_allreduce_ms
+        return 0.0 if self.solver or self.cfg in ("4shard", "2shard") else self.algo._ctx.last_allreduce_ms
 
     def result(self):
         return self.ctx.get_result(self.n, 1) if self.cfg == "4shard" else self.algo.get_result()
@@ -484,6 +496,9 @@ class Workload:
         return {
             "2": f"BASELINE config 2: {self.kernel} product, uniform-3D (uniform_cube seed n+D), N=M={n}, D=3, E=1, "
                  f"{self.precision}, same_points",
+            "2shard": f"BASELINE config 2, one of 8 source shards on one GPU (rank 4 of 8, sources sharded cell by cell): {n} "
+                      f"targets x {self.my_sources() if self.algo is not None else '?'} sources, gaussian, float32; the exchange is a "
+                      f"host-staged rehearsal with nothing added",
             "3": f"BASELINE config 3: exp(-r) attention (row-normalised), uniform points / sqrt(D), N=M={n}, D={D}, "
                  f"E={E}, bf16 MFMA tiles, same_points",
             "attn": f"not a BASELINE config (VERDICT r1 item 9): Gaussian attention (row-normalised), uniform-3D, "
@@ -537,6 +552,11 @@ def error_leg(W, a, meta):
         lo, hi = W.shard
         truth, _ = c_oracle.product(kernel=W.kernel, source_points=W.y[lo:hi], target_points=W.y, source_signal=W.b[lo:hi],
                                     rows=rows, j_offset=lo, M_total=W.n, raw_sums=True)
+    elif W.cfg == "2shard":
+        lo, hi = W.algo.shard
+        order = W.algo._order if W.algo._order is not None else np.arange(W.n)
+        truth = c_oracle.product(kernel=W.kernel, source_points=W.y[order][lo:hi], target_points=W.y, source_signal=W.b[order][lo:hi],
+                                 rows=rows)
     elif W.kernel == "exp-dot":
         import kmvp_oracle  # (the C restatement has the reference's three kernels; exp(<x,y>) is checked by direct evaluation)
 
@@ -563,6 +583,7 @@ def roofline_of(W, kname, k_ms, world=1):
     achieved = fpp * shard_pairs / (k_ms * 1e-3) / 1e12
     cfg = W.cfg
     tag = {"2": f"{'gaussian' if W.kernel == 'gaussian' else W.kernel}_1e6_{'f32' if W.precision == 'float32' else 'f64'}",
+           "2shard": "c2shard_gaussian_f32",
            "3": "c3_absexp_bf16", "4": "c4_invdist_1e7_f32", "4shard": "c4shard_invdist_f32", "5": "c5_gaussian_1e5_f64",
            "attn": "attn_gaussian_1e5_e16_f32", "softmax": "softmax_expdot_bf16"}[cfg]
     traffic, traffic_source = traffic_from_profile(kname, tag) if n == FULL_SIZE[cfg] and world == 1 else (None, None)
@@ -636,7 +657,7 @@ def measure_other_configs(args, device, np):
     # (the short launches need a long warm-up: after the idle seconds of the CPU baseline the chip takes ~50 ms of work to
     # return to its steady clock -- config 3: 1.30 ms per launch after 2 warm-up steps, 1.18 after 40, 1.10-1.12 in steady
     # state; profiles/r03_c3_variants.txt)
-    plan = (("3", 20, 50), ("softmax", 20, 50), ("attn", 20, 50), ("4shard", 2, 1), ("5", 1, 1))
+    plan = (("2shard", 10, 10), ("3", 20, 50), ("softmax", 20, 50), ("attn", 20, 50), ("4shard", 2, 1), ("5", 1, 1))
     out = {}
     for cfg, steps, warmup in plan:
         t_start = time.time()
@@ -696,7 +717,7 @@ def main(argv=None):
     # every rank checks the launch shape BEFORE anything touches a GPU, with a message that says what to change
     if distributed and world != args.gpus:
         raise SystemExit(f"[rank {rank}] --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
-    if args.config in ("4shard", "5", "3", "attn", "softmax") and args.gpus > 1:
+    if args.config in ("2shard", "4shard", "5", "3", "attn", "softmax") and args.gpus > 1:
         raise SystemExit(f"--config {args.config} is a single-GPU measurement")
     # the host driver of this pool only supports dmabuf IPC (RCCL across processes needs it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -746,8 +767,8 @@ def main(argv=None):
             dist.barrier()
 
     cfg = args.config
-    steps = args.steps if args.steps is not None else {"2": 10, "3": 10, "4shard": 3, "4": 2, "5": 2, "attn": 10, "softmax": 10}[cfg]
-    warmup = args.warmup if args.warmup is not None else {"2": 2, "3": 50, "attn": 50, "softmax": 50}.get(cfg, 1)
+    steps = args.steps if args.steps is not None else {"2": 10, "2shard": 10, "3": 10, "4shard": 3, "4": 2, "5": 2, "attn": 10, "softmax": 10}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"2": 2, "2shard": 10, "3": 50, "attn": 50, "softmax": 50}.get(cfg, 1)
 
     W = Workload(cfg, args, device, comm, np, n=args.n, sqdists=args.sqdists, kernel_arg=args.kernel,
                  precision_arg=args.precision)
@@ -767,7 +788,7 @@ def main(argv=None):
         seen = torch.tensor([rccl_ranks], dtype=torch.int64)
         dist.all_reduce(seen, op=dist.ReduceOp.MIN)
         rccl_ranks = int(seen[0])
-        if rccl_ranks != world:
+        if rccl_ranks != world and cfg != "2shard":
             raise SystemExit(f"[rank {rank}] the communicator spans {rccl_ranks} rank(s), expected {world}")
 
     # the other forms on the same resident data, for the record (config 2, one GPU, untimed region)
@@ -824,7 +845,8 @@ def main(argv=None):
                 "kernel_form": KERNEL_FORM.get(kname, "difference form (reference fast_sqdists=False)" if "lowd" in kname else kname),
             },
             "rccl_ranks": rccl_ranks,
-            "exchange": args.exchange if args.gpus > 1 else None,
+            "exchange": ("host-staged rehearsal as rank 4 of 8 with nothing added: rccl_ranks is that communicator's size"
+                         if cfg == "2shard" else (args.exchange if args.gpus > 1 else None)),
             "device_bytes": meta.get("device_bytes"),
             "max_abs_err": max_err,
             "max_rel_err": rel_err,
