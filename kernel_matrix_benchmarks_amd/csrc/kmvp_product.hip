@@ -1443,8 +1443,10 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
   double* part_main = (double*)c->part.p;
   double* part_rest = part_main + (size_t)segments * main_slots;
   // MFMA shape: 16x16x32 (cellmm16_kernel) sustains more under the power limit, but issues twice the MFMAs per flop:
-  // 1e6 points 27.7 -> 26.6 ms, 5e5 equal, 2e5 (smaller cells' tile groups) 1.73 -> 1.96 ms (tools/cellmm_shapes.py)
-  const int shape = c->opt_cellmm_shape >= 0 ? c->opt_cellmm_shape : ((TT >= 8 && (double)c->N * (double)c->M >= 4.0e11) ? 1 : 0);
+  // 1e6 points 27.7 -> 26.6 ms, 5e5 equal, 2e5 (smaller cells' tile groups) 1.73 -> 1.96 ms (tools/cellmm_shapes.py).  What
+  // counts is how full the TARGET cells are, not the pair count: one of eight ranks' share of config 2 (1e6 targets x 125 000
+  // sources) gains 3 % as well (3.72 -> 3.60 ms, tools/c2_shard.py --shape)
+  const int shape = c->opt_cellmm_shape >= 0 ? c->opt_cellmm_shape : ((TT >= 8 && c->N >= 500000 && c->M >= 100000) ? 1 : 0);
   CellmmArgs a;
   a.xd = (const float*)c->xs.p;
   a.tmeta = (const float*)c->cell_tmeta.p;

@@ -21,6 +21,7 @@ def main():
     p.add_argument("--worlds", default="1,2,4,8")
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--kernel", default="gaussian")
+    p.add_argument("--shape", type=int, default=-1, help="cellmm_shape option: -1 auto, 0 = 32x32x16, 1 = 16x16x32")
     a = p.parse_args()
     from kernel_matrix_benchmarks_amd import sharding
     from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct
@@ -36,6 +37,7 @@ def main():
             comm = sharding.Communicator(w // 2, w, lambda payload: payload, host_allreduce=lambda arr, op: None)
         algo = MI355XProduct(kernel=a.kernel, dimension=D, precision="float32", device=0, comm=comm)
         algo.prepare_data(source_points=y, target_points=y, same_points=True)
+        algo.set_query_arguments(cellmm_shape=a.shape)
         algo.fit()
         algo.prepare_query(source_signal=b)
         for _ in range(5):
