@@ -18,7 +18,8 @@ __device__ __forceinline__ void values(float (&v)[16], float& den, bf16x8 (&pa)[
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     float u = v[q];
-    if (trans >= 2) u = __builtin_amdgcn_sqrtf(__builtin_fabsf(u));
+    if (trans == 3) u = __builtin_fabsf(u) * __builtin_amdgcn_rsqf(__builtin_fabsf(u));  // s rsq(s) in place of sqrt(s)
+    else if (trans >= 2) u = __builtin_amdgcn_sqrtf(__builtin_fabsf(u));
     if (trans >= 1) u = __builtin_amdgcn_exp2f(-u);
     den += u;
     pa[q >> 3][q & 7] = (__bf16)u;
@@ -101,6 +102,7 @@ int main() {
   if (run<32, 1, 0>("VALU work alone (exp2)")) return 1;
   if (run<32, 0, 1>("9 x 32x32x16 + add/cvt only")) return 1;
   if (run<16, 0, 1>("20 x 16x16x32 + add/cvt only")) return 1;
+  if (run<32, 3, 1>("9 x 32x32x16 + s*rsq(s)/exp2/add/cvt        (VERDICT r2 item 3: same slot cost?)")) return 1;
   if (run<32, 2, 1>("9 x 32x32x16 + sqrt/exp2/add/cvt (again)")) return 1;
   return 0;
 }
