@@ -203,8 +203,9 @@ int kmvp_comm_init_host(kmvp_ctx* ctx, kmvp_host_allreduce_fn fn, void* user, in
  *   "fast_tiles"       target tiles of 32 per wavefront in that kernel: 0 = auto, 1, 2, 4, 8
  *                      (clamped to what is instantiated: fast_kernel 4 up to D = 7, 2 up to D = 23,
  *                      1 beyond; cfast_kernel 4; cell_kernel and cellmm_kernel 8) */
-/*   "cellmm_shape"     MFMA shape of the float32 cell form: -1 = by size (default: 16x16x32 from N M >= 4e11 on with eight
- *                      target tiles per wave, else 32x32x16), 0 = 32x32x16 (cellmm_kernel), 1 = 16x16x32 (cellmm16_kernel)
+/*   "cellmm_shape"     MFMA shape of the float32 cell form: -1 = by size (default: 16x16x32 from 5e5 targets and 1e5 sources
+ *                      on with eight target tiles per wave, else 32x32x16), 0 = 32x32x16 (cellmm_kernel), 1 = 16x16x32
+ *                      (cellmm16_kernel)
  *   "mfma_variant"     bf16 path, software-pipelined kernel: -1 = by kernel (default: exp(-r) 4, others 0), 0 = plain,
  *                      1 = denominators on the matrix pipe (one more accumulator tile per target tile), 4 = loop rotated by one
  *                      transcendental stage, 5 = both (csrc/kmvp_mfma.hpp, mfma_pipe_kernel VAR) */
