@@ -2187,3 +2187,33 @@ def test_multi_column_kernels_as_solver_operators(kernel, side, want_kernel):
         assert res <= 2 * rtol, (res, info)
     else:  # an ill-conditioned draw: it must have said so, with a residual that is the true one
         assert info["cg_relative_residual"] > rtol and abs(res - info["cg_relative_residual"]) <= 0.5 * res, (res, info)
+
+
+@pytest.mark.parametrize("config,points,tol", [("2", 60000, 1e-5), ("2shard", 200000, 1e-5), ("3", 4096, 1e-2), ("softmax", 4096, 1e-2),
+                                               ("attn", 20000, 1e-5), ("4shard", 200000, 2e-4), ("5", 6000, None)])
+def test_bench_configs_at_reduced_size(config, points, tol):
+    """`python bench.py --config C --points n` for every config the default run reports (headline and `other_configs`): one
+    JSON line with the contract's keys, a roofline object, the error leg inside the working precision's tolerance (solver: the
+    residual on the oracle rows).  The default-size numbers are the driver's; this keeps every config's code path alive."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--points", str(points), "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic"
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "valu", "hbm") and r["achieved"] > 0 and 0 < r["frac"] < 1.0 and r["kernel"].endswith("_kernel")
+    if tol is not None:
+        assert d["max_rel_err"] <= tol, d["max_rel_err"]
+    else:
+        assert d["solver"]["converged"] and d["solver"]["residual_rows"] <= 2e-6, d["solver"]
