@@ -90,14 +90,40 @@ real scale_for(int kernel) {
   }
 }
 
-// sums[e][i] = sum over segments (index order) of part[s][e][i]
-__global__ void reduce_segments_kernel(const double* __restrict__ part, double* __restrict__ sums,
-                                       int64_t count /* NE*n_pad */, int segments) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= count) return;
+// Sum over the segments of part[s * stride + q].  Few segments: one thread per sum, index order.  Many (small problems take
+// ~100 segments to fill the chip, and one thread's chain of dependent loads then costs more than the pair loop of a 1e4-point
+// product): SEG_SPLIT consecutive lanes share a sum -- lane g takes the segments s = g (mod SEG_SPLIT) in index order, a
+// butterfly over the group adds the eight partial sums.  A fixed order either way: results stay bitwise reproducible, and
+// reduce_segments_kernel (the exchange path) and reduce_finish_kernel (the plain one) add in the SAME order.
+constexpr int SEG_SPLIT = 8;
+constexpr int SEG_SPLIT_FROM = 16;  // segments from which the split form is taken
+__device__ __forceinline__ double seg_sum_one(const double* __restrict__ part, int64_t stride, int64_t q, int segments) {
   double v = 0.0;
-  for (int s = 0; s < segments; ++s) v += part[(int64_t)s * count + q];
-  sums[q] = v;
+  for (int s = 0; s < segments; ++s) v += part[(int64_t)s * stride + q];
+  return v;
+}
+__device__ __forceinline__ double seg_sum_split(const double* __restrict__ part, int64_t stride, int64_t q, int segments, int g) {
+  double v = 0.0;
+  for (int s = g; s < segments; s += SEG_SPLIT) v += part[(int64_t)s * stride + q];
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+
+// sums[e][i] = sum over segments of part[s][e][i]  (split != 0: SEG_SPLIT threads per sum, launched accordingly)
+__global__ void reduce_segments_kernel(const double* __restrict__ part, double* __restrict__ sums,
+                                       int64_t count /* NE*n_pad */, int segments, int split) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (split) {
+    const int64_t q = t / SEG_SPLIT;
+    if (q >= count) return;  // (whole groups leave together)
+    const double v = seg_sum_split(part, count, q, segments, (int)(t % SEG_SPLIT));
+    if (t % SEG_SPLIT == 0) sums[q] = v;
+    return;
+  }
+  if (t >= count) return;
+  sums[t] = seg_sum_one(part, count, t, segments);
 }
 
 // The same for one launch's REGION of partial sums [segment][column][region_slots] (the float32 cell kernels run two
@@ -116,19 +142,19 @@ __global__ void reduce_region_kernel(const double* __restrict__ part, double* __
 // part[s][e][i], divided by the same sum of column E when normalised.  Same additions in the
 // same order as reduce_segments_kernel + finish_kernel.
 __global__ void reduce_finish_kernel(const double* __restrict__ part, double* __restrict__ out, int64_t n,
-                                     int64_t n_pad, int E, int NE, int segments, int normalise) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                     int64_t n_pad, int E, int NE, int segments, int normalise, int split) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = split ? t / SEG_SPLIT : t;
+  const int g = split ? (int)(t % SEG_SPLIT) : 0;
+  if (i >= n) return;  // (split: whole groups leave together)
   const int64_t count = (int64_t)NE * n_pad;
   double den = 1.0;
-  if (normalise) {
-    den = 0.0;
-    for (int s = 0; s < segments; ++s) den += part[(int64_t)s * count + (int64_t)E * n_pad + i];
-  }
+  if (normalise)
+    den = split ? seg_sum_split(part, count, (int64_t)E * n_pad + i, segments, g) : seg_sum_one(part, count, (int64_t)E * n_pad + i, segments);
   for (int e = 0; e < E; ++e) {
-    double v = 0.0;
-    for (int s = 0; s < segments; ++s) v += part[(int64_t)s * count + (int64_t)e * n_pad + i];
-    out[i * E + e] = normalise ? v / den : v;
+    const double v = split ? seg_sum_split(part, count, (int64_t)e * n_pad + i, segments, g)
+                           : seg_sum_one(part, count, (int64_t)e * n_pad + i, segments);
+    if (g == 0) out[i * E + e] = normalise ? v / den : v;
   }
 }
 
@@ -301,16 +327,17 @@ int finish_product_shifted(kmvp_ctx* c, int64_t N, int64_t n_pad, int E, int sig
 int reduce_and_finish(kmvp_ctx* c, int segments, int NE, int64_t N, int64_t n_pad, int E, int sig) {
   int rc;
   const int64_t count = (int64_t)NE * n_pad;
+  const int split = segments >= SEG_SPLIT_FROM ? 1 : 0;
   if (c->exchanges()) {
     if ((rc = ensure(c, c->sums, (size_t)count * sizeof(double)))) return rc;
-    hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,
-                       (const double*)c->part.p, (double*)c->sums.p, count, segments);
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(count * (split ? SEG_SPLIT : 1))), dim3(256), 0, c->stream,
+                       (const double*)c->part.p, (double*)c->sums.p, count, segments, split);
     HIP_TRY(c, hipGetLastError());
     return finish_product(c, count, N, n_pad, E, sig);
   }
   if ((rc = ensure(c, c->out, (size_t)std::max<int64_t>(N, 1) * E * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(reduce_finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1))), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->out.p, N, n_pad, E, NE, segments, sig == SIG_NORM ? 1 : 0);
+  hipLaunchKernelGGL(reduce_finish_kernel, dim3(blocks_for(std::max<int64_t>(N, 1) * (split ? SEG_SPLIT : 1))), dim3(256), 0, c->stream,
+                     (const double*)c->part.p, (double*)c->out.p, N, n_pad, E, NE, segments, sig == SIG_NORM ? 1 : 0, split);
   HIP_TRY(c, hipGetLastError());
   c->out_n = N;
   c->out_e = E;
@@ -1495,10 +1522,10 @@ int run_product_cellmm(kmvp_ctx* c, int sig) {
     double* col_sums = (double*)c->cell_sums.p + (size_t)col * n_slots;
     if (tile_blocks > 0)
       hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(main_slots)), dim3(256), 0, c->stream,
-                         (const double*)part_main, col_sums, main_slots, segments);
+                         (const double*)part_main, col_sums, main_slots, segments, 0);
     if (rest_blocks > 0)
       hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for(rest_slots)), dim3(256), 0, c->stream,
-                         (const double*)part_rest, col_sums + main_slots, rest_slots, rest_segments);
+                         (const double*)part_rest, col_sums + main_slots, rest_slots, rest_segments, 0);
     HIP_TRY(c, hipGetLastError());
   }
   if (NE > 1) HIP_TRY(c, mark(c, 1));  // several columns: the "kernel" time covers every column's pack + pair loop
@@ -1621,7 +1648,7 @@ int run_product_cell64(kmvp_ctx* c, int sig) {
   if ((rc = ensure(c, c->sums, (size_t)NE * N * sizeof(double)))) return rc;
   if ((rc = ensure(c, c->cell_sums, (size_t)NE * n_slots * sizeof(double)))) return rc;
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(blocks_for((int64_t)NE * n_slots)), dim3(256), 0, c->stream,
-                     (const double*)c->part.p, (double*)c->cell_sums.p, (int64_t)NE * n_slots, segments);
+                     (const double*)c->part.p, (double*)c->cell_sums.p, (int64_t)NE * n_slots, segments, 0);
   hipLaunchKernelGGL(gather_cells_kernel, dim3(blocks_for((int64_t)NE * N)), dim3(256), 0, c->stream,
                      (const double*)c->cell_sums.p, (const int*)c->cell_slot.p, (double*)c->sums.p, N, n_slots, NE);
   HIP_TRY(c, hipGetLastError());
