@@ -102,15 +102,20 @@ __device__ __forceinline__ double kval(double s, const double* __restrict__ tab)
   if constexpr (KERNEL == K_GAUSSIAN) {
     return kexp_neg_f64(s, tab);
   } else if constexpr (KERNEL == K_ABSEXP) {
-    return kexp_neg_f64(sqrt(s), tab);
-  } else {
-    // 1/sqrt(s): hardware estimate (v_rsq_f64, ~26 bits) + two Newton steps; the estimate is
-    // already exact for s = 0 (inf, as the reference's 1/np.sqrt) and s = inf (0, pad records)
+    // sqrt(s) = s / sqrt(s) from the same estimate-and-one-step as 1/sqrt(s) below (the compiler's IEEE sqrt spends about
+    // twice the instructions on scaling and a second correction; s is a sum of squares: never negative, denormal only
+    // where the result is far below every tolerance); s = 0 and s = inf (pad records) pass through
     const double y0 = __builtin_amdgcn_rsq(s);
-    double e = fma(-s * y0, y0, 1.0);
-    double y = fma(y0 * e, 0.5, y0);
-    e = fma(-s * y, y, 1.0);
-    y = fma(y * e, 0.5, y);
+    const double e = fma(-s * y0, y0, 1.0);
+    const double r = s * fma(y0 * e, fma(e, 0.375, 0.5), y0);
+    return kexp_neg_f64((s == 0.0 || s == (double)INFINITY) ? s : r, tab);
+  } else {
+    // 1/sqrt(s): hardware estimate (v_rsq_f64, ~26 bits) + ONE Newton step in its third-order form
+    // y = y0 (1 + e/2 + 3 e^2/8), e = 1 - s y0^2 (|e| <= 2^-25: the neglected term 5 e^3/16 is below 2^-76); the
+    // estimate is already exact for s = 0 (inf, as the reference's 1/np.sqrt) and s = inf (0, pad records)
+    const double y0 = __builtin_amdgcn_rsq(s);
+    const double e = fma(-s * y0, y0, 1.0);
+    const double y = fma(y0 * e, fma(e, 0.375, 0.5), y0);
     return (s == 0.0 || s == (double)INFINITY) ? y0 : y;
   }
 }
