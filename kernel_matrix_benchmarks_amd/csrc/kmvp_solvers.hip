@@ -453,11 +453,12 @@ enum : int { MS_BETA1 = 0, MS_BETA, MS_OLDB, MS_ALFA, MS_DBAR, MS_EPSLN, MS_CS, 
 __host__ __device__ inline size_t ms_triple(int E, int t) { return (size_t)MS_FIELDS * E + (size_t)t * 3 * E; }
 __host__ __device__ inline size_t ms_stop(int E) { return (size_t)MS_FIELDS * E + 15 * (size_t)E; }
 
-// out = c0 a + c1 b + c2 c with the coefficient triple in device memory; nothing once stopped
-__global__ void vec_lin3_dev_kernel(double* __restrict__ out, const double* __restrict__ a,
+// out = c0 a + c1 b + c2 c with the coefficient triple in device memory; nothing once stopped.  out2 (or nullptr): a second
+// copy of the result -- it may be `a` itself (each thread reads its element before it writes it)
+__global__ void vec_lin3_dev_kernel(double* __restrict__ out, const double* a,
                                     const double* __restrict__ b, const double* __restrict__ c,
                                     const double* __restrict__ coef, const double* __restrict__ stop, int64_t m,
-                                    int E) {
+                                    int E, double* out2) {
   if (*stop != 0.0) return;
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= m * E) return;
@@ -466,13 +467,28 @@ __global__ void vec_lin3_dev_kernel(double* __restrict__ out, const double* __re
   if (b) v += coef[E + e] * b[q];
   if (c) v += coef[2 * E + e] * c[q];
   out[q] = v;
+  if (out2) out2[q] = v;
 }
 
-__global__ void vec_copy_dev_kernel(double* __restrict__ out, const double* __restrict__ in,
-                                    const double* __restrict__ stop, int64_t count) {
+// The three vector updates that close a MINRES iteration, in one launch (each was a ~4.5 us kernel of its own in a solve whose
+// iteration is a chain of such kernels): w = T3 . (v, w1, w2);  x = T4 . (x, w);  v = T0 y  (the NEXT iteration's Lanczos vector;
+// v is read for w before it is overwritten, element by element).  Same expressions, same order as vec_lin3_dev_kernel.
+__global__ void minres_tail_kernel(double* __restrict__ w, double* __restrict__ v, const double* __restrict__ w1,
+                                   const double* __restrict__ w2, double* __restrict__ x, const double* __restrict__ y,
+                                   const double* __restrict__ T3, const double* __restrict__ T4, const double* __restrict__ T0,
+                                   const double* __restrict__ stop, int64_t m, int E) {
   if (*stop != 0.0) return;
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < count) out[q] = in[q];
+  if (q >= m * E) return;
+  const int e = (int)(q % E);
+  double wv = T3[e] * v[q];
+  wv += T3[E + e] * w1[q];
+  wv += T3[2 * E + e] * w2[q];
+  w[q] = wv;
+  double xv = T4[e] * x[q];
+  xv += T4[E + e] * wv;
+  x[q] = xv;
+  v[q] = T0[e] * y[q];
 }
 
 // mode 1 (after v.y): alfa, T2 = (1, -alfa/beta, 0).
@@ -634,16 +650,17 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
   };
   auto dlin3 = [&](double* out, const double* pa, const double* pb, const double* pc, int triple) {
     hipLaunchKernelGGL(vec_lin3_dev_kernel, dim3(vb), dim3(256), 0, c->stream, out, pa, pb, pc,
-                       st + ms_triple(E, triple), stop, m, E);
+                       st + ms_triple(E, triple), stop, m, E, (double*)nullptr);
   };
 
   int it = 0;
   double rel = worst();
   c->async_product = true;
+  dlin3(v, y, nullptr, nullptr, 0);  // v = y / beta of the first iteration
   while (it < maxit && rel > rtol) {
     const int burst = std::min(CG_CHECK, maxit - it);
     for (int k = 0; k < burst; ++k) {
-      dlin3(v, y, nullptr, nullptr, 0);  // v = y / beta
+      // (v = y / beta was written by the previous iteration's tail, or before the loop)
       if ((rc = cg_apply(c, kernel, v, m, E))) {
         c->async_product = false;
         return rc;
@@ -651,9 +668,10 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
       dlin3(y, (const double*)c->out.p, r1, nullptr, 1);  // y = K v - (beta / oldb) r1
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, v, y, m, E, wk.partial);
       hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(CG_BLOCKS), 0, c->stream, wk.partial, st, E, 1, rtol);
-      dlin3(r1, y, r2, nullptr, 2);  // y - (alfa / beta) r2, written into the old r1 buffer
+      // y - (alfa / beta) r2, written into the old r1 buffer AND back into y
+      hipLaunchKernelGGL(vec_lin3_dev_kernel, dim3(vb), dim3(256), 0, c->stream, r1, (const double*)y, (const double*)r2,
+                         (const double*)nullptr, st + ms_triple(E, 2), stop, m, E, y);
       std::swap(r1, r2);             // r1 <- r2, r2 <- the new vector
-      hipLaunchKernelGGL(vec_copy_dev_kernel, dim3(vb), dim3(256), 0, c->stream, y, r2, stop, (int64_t)n);
       hipLaunchKernelGGL(cg_dot_kernel, dim3(CG_BLOCKS), dim3(256), 0, c->stream, r2, r2, m, E, wk.partial);
       hipLaunchKernelGGL(minres_scalars_kernel, dim3(1), dim3(CG_BLOCKS), 0, c->stream, wk.partial, st, E, 2, rtol);
       {  // w_new = (v - oldeps w1 - delta w2) / gamma with w1 <- w2, w2 <- w
@@ -662,8 +680,9 @@ int minres_solve(kmvp_ctx* c, int kernel, const void* a_host, int E, double rtol
         w2 = w;
         w = t;
       }
-      dlin3(w, v, w1, w2, 3);
-      dlin3(x, x, w, nullptr, 4);  // x = x + phi w
+      // w = T3 . (v, w1, w2);  x = x + phi w;  v = y / beta for the next iteration
+      hipLaunchKernelGGL(minres_tail_kernel, dim3(vb), dim3(256), 0, c->stream, w, v, (const double*)w1, (const double*)w2, x,
+                         (const double*)y, st + ms_triple(E, 3), st + ms_triple(E, 4), st + ms_triple(E, 0), stop, m, E);
     }
     hipError_t le = hipGetLastError();
     if (le == hipSuccess) le = hipMemcpyAsync(state.data(), st, sizeof(double) * st_len, hipMemcpyDeviceToHost, c->stream);
