@@ -54,6 +54,9 @@ hipError_t launch_mfma_invdist(int KS, int NT, int TW, const MfmaArgs& args, dim
 // exp(<x,y>) with the per-target running shift (kmvp_mfma.hpp; D <= 16 KS - 3)
 hipError_t launch_mfma_expdot(int KS, int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream,
                               const char** kernel_name);
+// the Gaussian with the same shift (targets != sources; D <= 16 KS - 9)
+hipError_t launch_mfma_gaussian_shifted(int KS, int NT, int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream,
+                                        const char** kernel_name);
 
 
 // split-bf16 MFMA low-D path (kmvp_fast.hpp): 6 D + 6 <= 48, E == 1

@@ -33,7 +33,9 @@
 
 namespace kmvp {
 
-enum : int { K_GAUSSIAN = 0, K_ABSEXP = 1, K_INVDIST = 2, K_EXPDOT = 3 };  // K_EXPDOT: host-side only (run_product)
+enum : int { K_GAUSSIAN = 0, K_ABSEXP = 1, K_INVDIST = 2, K_EXPDOT = 3, K_GAUSSIAN_SHIFTED = 4 };
+// K_EXPDOT: host-side only (run_product) and the bf16 matrix-core kernels; K_GAUSSIAN_SHIFTED: the bf16 matrix-core kernels
+// only -- the Gaussian with exp(<x,y>)'s per-target running shift, taken when targets != sources (kmvp_mfma.hpp)
 
 // signal mode of a launch
 enum : int {

@@ -60,6 +60,13 @@ __host__ __device__ constexpr int mfma_ksteps(int D) { return (D + MFMA_AUG + 15
 //   target i :  [ x_i (D) , 0.. , -m_hi , -m_lo , 1                ]        S[j][i] = <x_i, y_j> log2(e) - m_i
 constexpr int MFMA_DOT_AUG = 3;
 __host__ __device__ constexpr int mfma_ksteps_dot(int D) { return (D + MFMA_DOT_AUG + 15) / 16; }
+// the Gaussian with the same shift (K_GAUSSIAN_SHIFTED): the six norm columns as above, the shift in columns 16 KS - 3 / - 2
+//   source j :  [ -2 y, |y|^2 (3), 1, 1, 1, 0.. , 1    , 1    , 0 ]
+//   target i :  [    x, 1, 1, 1, |x|^2 (3), 0.. , m_hi , m_lo , 0 ]        S[j][i] = |x_i - y_j|^2 + m_i ,  p = 2^-S
+__host__ __device__ constexpr int mfma_ksteps_shifted(int D) { return (D + MFMA_AUG + MFMA_DOT_AUG + 15) / 16; }
+// kernels that carry the per-target running shift, and the sign of S in log2(p) = SGN * S
+template <int KERNEL> __host__ __device__ constexpr bool mfma_online() { return KERNEL == K_EXPDOT || KERNEL == K_GAUSSIAN_SHIFTED; }
+template <int KERNEL> __host__ __device__ constexpr int mfma_sgn() { return KERNEL == K_EXPDOT ? 1 : -1; }
 __host__ __device__ constexpr int mfma_y_stride(int KS) { return KS * 32 + 16; }  // bytes per source row
 // bytes of one tile image, rounded up to a whole number of 16-byte pieces per thread of
 // the copying workgroup (no predication in the staging loop)
@@ -84,7 +91,7 @@ struct MfmaArgs {
 
 template <int KERNEL>
 __device__ __forceinline__ float mfma_kval(float s) {
-  if constexpr (KERNEL == K_GAUSSIAN) {
+  if constexpr (KERNEL == K_GAUSSIAN || KERNEL == K_GAUSSIAN_SHIFTED) {
     return kexp2(-s);
   } else if constexpr (KERNEL == K_ABSEXP) {
     // |s| instead of max(s, 0): a free source modifier.  s < 0 only by rounding noise of the
@@ -107,7 +114,7 @@ __device__ __forceinline__ float mfma_kval_stage1(float s) {
 }
 template <int KERNEL>
 __device__ __forceinline__ float mfma_kval_stage2(float u) {
-  if constexpr (KERNEL == K_GAUSSIAN) return kexp2(-u);
+  if constexpr (KERNEL == K_GAUSSIAN || KERNEL == K_GAUSSIAN_SHIFTED) return kexp2(-u);
   else if constexpr (KERNEL == K_ABSEXP) return kexp2(-u);
   else if constexpr (KERNEL == K_EXPDOT) return kexp2(u);
   else return __builtin_amdgcn_rsqf(__builtin_fabsf(u));
@@ -147,12 +154,13 @@ constexpr float MFMA_DOT_MAX_SHIFT = 32000.f;    // |m| < 2^15: m_hi / 128 and m
 // s_next: the next source tile's, if already computed; o: the tile's output accumulators (row acc_row(q, h) = target);
 // den: this lane's partial denominator; m: the target's shift; xlast: the target's operand of the last k-step; scratch:
 // 32 floats of LDS owned by the wave.
-template <int NT>
+// SGN: log2 of a kernel value is SGN * s (+1: exp(<x,y>), s = logit - m; -1: the shifted Gaussian, s = distance^2 + m).
+template <int NT, int SGN>
 __device__ __forceinline__ void mfma_dot_event(bool first, f32x16& s, f32x16* s_next, f32x16 (&o)[NT], float& den, float& m,
                                                bf16x8& xlast, float* scratch, int r, int h) {
-  float tmax = s[0];
+  float tmax = (float)SGN * s[0];
 #pragma unroll
-  for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, s[q]);
+  for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, (float)SGN * s[q]);
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
   float delta = ceilf(tmax);                       // the tile's largest value becomes <= 1
   if (!first) {
@@ -166,10 +174,10 @@ __device__ __forceinline__ void mfma_dot_event(bool first, f32x16& s, f32x16* s_
   delta = m_new - m;
   m = m_new;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) s[q] -= delta;
+  for (int q = 0; q < 16; ++q) s[q] -= (float)SGN * delta;
   if (s_next != nullptr) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) (*s_next)[q] -= delta;
+    for (int q = 0; q < 16; ++q) (*s_next)[q] -= (float)SGN * delta;
   }
   const int di = (int)delta;
   den = ldexpf(den, -di);
@@ -186,9 +194,9 @@ __device__ __forceinline__ void mfma_dot_event(bool first, f32x16& s, f32x16* s_
   }
   __builtin_amdgcn_wave_barrier();
   const float m_hi = 128.f * truncf(m_new * (1.f / 128.f));
-  if (h == 1) {  // k = 16 KS - 3 and 16 KS - 2: elements 5 and 6 of the upper lane half's fragment
-    xlast[5] = (__bf16)(-m_hi);
-    xlast[6] = (__bf16)(m_hi - m_new);
+  if (h == 1) {  // k = 16 KS - 3 and 16 KS - 2: elements 5 and 6 of the upper lane half's fragment; s = ... - SGN m
+    xlast[5] = (__bf16)((float)-SGN * m_hi);
+    xlast[6] = (__bf16)((float)-SGN * (m_new - m_hi));
   }
 }
 
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
   f32x16 o[TW][NT];
   float den[TW];
   // exp(<x,y>): the targets' shifts, whether a tile has set them yet, and the wave's LDS scratch of an event
-  constexpr bool DOT = KERNEL == K_EXPDOT;
+  constexpr bool DOT = mfma_online<KERNEL>();
   __shared__ __attribute__((aligned(16))) float dscr[DOT ? WPB : 1][DOT ? MFMA_TILE : 1];
   float msh[TW];
   bool unset[TW];
@@ -337,7 +345,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
       }
       if constexpr (DOT) {
         if (unset[w] || __any(!(den[w] + dsum < MFMA_DOT_LIMIT))) {  // wave-uniform, rare after the first tile
-          mfma_dot_event<NT>(unset[w], s, nullptr, o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
+          mfma_dot_event<NT, mfma_sgn<KERNEL>()>(unset[w], s, nullptr, o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
           unset[w] = false;
           dsum = 0.f;
 #pragma unroll
@@ -413,8 +421,8 @@ template <int KERNEL, int KS, int NT, int VAR = 0>
 __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs a) {
   constexpr bool DEN_MFMA = (VAR & 1) != 0;
   constexpr bool ROTATE = (VAR & 4) != 0;
-  constexpr bool DOT = KERNEL == K_EXPDOT;
-  static_assert(!DOT || VAR == 0, "exp(<x,y>): the running shift is built into the plain pipeline only");
+  constexpr bool DOT = mfma_online<KERNEL>();
+  static_assert(!DOT || VAR == 0, "the running shift is built into the plain pipeline only");
   static_assert((VAR & 2) == 0, "bit 1 was the deferred-P.V arm: measured 5 % slower and removed (LAB_NOTES.md)");
   constexpr int TW = 2;
   constexpr int KD = 16 * KS;
@@ -675,7 +683,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
         // (kmvp_mfma.hpp "the per-target running shift"; the distances of tile t + 1 are already on their way with the old
         // operand: the event lowers them too)
         if (unset[w] || __any(!(den[w] + dsum < MFMA_DOT_LIMIT))) {
-          mfma_dot_event<NT>(unset[w], s_cur[w], &s_next[w], o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
+          mfma_dot_event<NT, mfma_sgn<KERNEL>()>(unset[w], s_cur[w], &s_next[w], o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
           unset[w] = false;
           dsum = 0.f;
 #pragma unroll

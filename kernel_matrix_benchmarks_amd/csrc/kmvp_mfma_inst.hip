@@ -1,5 +1,6 @@
-// Instantiations of the bf16 MFMA kernel for ONE kernel function (compiled four times,
-// -DKMVP_KERNEL={0,1,2,3} -DKMVP_FN=launch_mfma_<kernel>; 3 = exp(<x,y>): D <= 16*KS - 3): KS = k-steps of the augmented
+// Instantiations of the bf16 MFMA kernel for ONE kernel function (compiled five times,
+// -DKMVP_KERNEL={0,1,2,3,4} -DKMVP_FN=launch_mfma_<kernel>; 3 = exp(<x,y>): D <= 16*KS - 3; 4 = the shifted Gaussian:
+// D <= 16*KS - 9): KS = k-steps of the augmented
 // point dimension (D <= 16*KS - 6), NT = 32-column tiles of the signal (E <= 32*NT).
 #include <stdlib.h>
 #include "kmvp_internal.hpp"
@@ -26,7 +27,7 @@ template <int KS, int NT>
 static hipError_t launch_one(int TW, const MfmaArgs& args, dim3 grid, hipStream_t stream) {
   if constexpr (KS <= MFMA_PIPE_MAX_KS && NT <= MFMA_PIPE_MAX_NT) {
     if (TW >= 3) {  // two target tiles per wave, software-pipelined; TW - 3 = variant (kmvp_mfma.hpp VAR)
-      if constexpr (KMVP_KERNEL == K_EXPDOT) {  // the running shift lives in the plain pipeline only
+      if constexpr (mfma_online<KMVP_KERNEL>()) {  // the running shift lives in the plain pipeline only
         launch_pipe(mfma_pipe_kernel<KMVP_KERNEL, KS, NT, 0>, args, grid, stream);
       } else {
         switch (TW - 3) {

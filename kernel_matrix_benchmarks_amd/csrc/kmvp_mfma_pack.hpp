@@ -17,13 +17,14 @@ __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16&
 
 // targets (N,D) f32 -> augmented bf16 rows [n_pad][KD]; pad targets are the origin (S = |y|^2: finite against live
 // sources, +inf against pad sources -- an all-zero row would make that inf x 0 = NaN)
-// dot != 0 (exp(<x,y>), kmvp_mfma.hpp MFMA_DOT_AUG): [x, 0.., -m_hi = 0, -m_lo = 0, 1]; pad targets are the origin.
+// dot == 1 (exp(<x,y>), kmvp_mfma.hpp MFMA_DOT_AUG): [x, 0.., -m_hi = 0, -m_lo = 0, 1]; pad targets are the origin.
+// dot == 2 (the shifted Gaussian): the plain layout, whose zeros at 16 KS - 3 / - 2 are the initial shift.
 __global__ void pack_mfma_targets_kernel(const float* __restrict__ x, __bf16* __restrict__ xa,
                                          int64_t n, int64_t n_pad, int D, int KD, float scale, int dot) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pad) return;
   __bf16* row = xa + i * KD;
-  if (dot) {
+  if (dot == 1) {
     for (int k = 0; k < KD; ++k) row[k] = (__bf16)((k < D && i < n) ? x[i * D + k] * scale : (k == KD - 1 ? 1.f : 0.f));
     return;
   }
@@ -63,7 +64,7 @@ __global__ void pack_mfma_sources_kernel(const float* __restrict__ y, const floa
   unsigned char* base = img + t * (int64_t)mfma_image_bytes(KS, NT);
   __bf16* row = reinterpret_cast<__bf16*>(base + jr * YS);
   const bool live = j < m;
-  if (dot) {
+  if (dot == 1) {
     // exp(<x,y>): [y, 0.., 1, 1, mask]; a pad source gets -3e38 through the targets' column of ones: 2^(-3e38 - m) = 0
     // (finite on purpose: -inf would turn a non-finite target coordinate's 0 x inf into NaN for the whole row)
     for (int k = 0; k < KD + 8; ++k) row[k] = (__bf16)((k < D && live) ? y[j * D + k] * scale : 0.f);
@@ -86,6 +87,10 @@ __global__ void pack_mfma_sources_kernel(const float* __restrict__ y, const floa
     row[D + 4] = (__bf16)1.f;
     row[D + 5] = (__bf16)1.f;
     for (int k = D + MFMA_AUG; k < KD + 8; ++k) row[k] = (__bf16)0.f;  // incl. the 16-byte row pad
+    if (dot == 2) {  // the shifted Gaussian: ones against the targets' two shift columns (kmvp_mfma.hpp mfma_ksteps_shifted)
+      row[KD - 3] = (__bf16)1.f;
+      row[KD - 2] = (__bf16)1.f;
+    }
   }
   unsigned char* vt = base + MFMA_TILE * YS;
   for (int e = 0; e < NT * 32; ++e) {

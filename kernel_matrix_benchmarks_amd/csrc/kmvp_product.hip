@@ -1664,15 +1664,24 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   const int64_t N = c->N, M = c->M;
   // exp(<x,y>) (include/kmvp.h kmvp_expdot, bfloat16): S = X Y^T log2(e) straight from the matrix pipe, the per-target
   // running shift of kmvp_mfma.hpp, partial sums as (mantissa, exponent) pairs and the shifted tail
-  const bool dot = kernel == K_EXPDOT;
-  const int KS = dot ? mfma_ksteps_dot(D) : mfma_ksteps(D);
+  // The Gaussian with targets != sources takes the same running shift (K_GAUSSIAN_SHIFTED): a target farther than ~9 kernel
+  // lengths from every source would otherwise have its whole row under the float32 range (0, or 0/0 when normalised) -- the
+  // bf16 counterpart of what fastmm_kernel / cfastmm_kernel do for float32.  Targets == sources keep the plain kernel (every
+  // row contains k = 1); exp(-r) would need r > 87 and stays plain.
+  const bool shifted = kernel == K_GAUSSIAN && !(c->same_points || c->opt_same_global) && c->opt_mfma_variant < 0 &&
+                       mfma_ksteps_shifted(D) <= MFMA_MAX_KS;  // (an explicit "mfma_variant" asks for the plain kernel)
+  if (shifted) kernel = K_GAUSSIAN_SHIFTED;
+  const bool dot = kernel == K_EXPDOT || shifted;  // (mantissa, exponent) partial sums and the shifted tail
+  const int KS = kernel == K_EXPDOT ? mfma_ksteps_dot(D) : (shifted ? mfma_ksteps_shifted(D) : mfma_ksteps(D));
   const int NT = (E + 31) / 32;
   if (KS > MFMA_MAX_KS || NT > MFMA_MAX_NT)
     return fail(c, KMVP_E_UNSUPPORTED, "bf16 MFMA path is instantiated for D <= 138 (exp(<x,y>): 141) and E <= 128");
   const int KD = 16 * KS;
   const int NEP = NT * 32;
   const int64_t IMG = mfma_image_bytes(KS, NT);
-  const float scale = dot ? 1.2011224087864498f /* sqrt(log2 e) on both sides */ : scale_for<float>(kernel);
+  const float scale = kernel == K_EXPDOT ? 1.2011224087864498f /* sqrt(log2 e) on both sides */
+                                         : scale_for<float>(shifted ? (int)K_GAUSSIAN : kernel);
+  const int pack_mode = kernel == K_EXPDOT ? 1 : (shifted ? 2 : 0);
   const float* x_raw = (const float*)(c->same_points ? c->y_raw.p : c->x_raw.p);
   // target tiles of 32 per wave ("targets_per_lane" option): 1, 2, or (default, where instantiated)
   // 2 with the software-pipelined kernel
@@ -1703,14 +1712,14 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   if (pts_stale) {
     if ((rc = ensure(c, c->xs, (size_t)n_pad * KD * 2))) return rc;
     hipLaunchKernelGGL(pack_mfma_targets_kernel, dim3(blocks_for(n_pad)), dim3(256), 0, c->stream,
-                       x_raw, (__bf16*)c->xs.p, N, n_pad, D, KD, scale, dot ? 1 : 0);
+                       x_raw, (__bf16*)c->xs.p, N, n_pad, D, KD, scale, pack_mode);
   }
   if (sig_stale) {
     if ((rc = ensure(c, c->rec, (size_t)m_tiles * IMG))) return rc;
     hipLaunchKernelGGL(pack_mfma_sources_kernel, dim3(blocks_for(m_tiles * MFMA_TILE)), dim3(256), 0,
                        c->stream, (const float*)c->y_raw.p,
                        sig == SIG_DENSITY ? (const float*)nullptr : (const float*)c->b_raw.p,
-                       (unsigned char*)c->rec.p, M, m_tiles, D, E, KS, NT, scale, dot ? 1 : 0);
+                       (unsigned char*)c->rec.p, M, m_tiles, D, E, KS, NT, scale, pack_mode);
   }
   HIP_TRY(c, hipGetLastError());
   c->packed_points_ver = c->points_ver;
@@ -1745,6 +1754,7 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
   hipError_t le;
   switch (kernel) {
     case K_EXPDOT: le = launch_mfma_expdot(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
+    case K_GAUSSIAN_SHIFTED: le = launch_mfma_gaussian_shifted(KS, NT, pipelined ? 3 : TW, a, grid, c->stream, &c->last_kernel_name); break;
     case K_GAUSSIAN: le = launch_mfma_gaussian(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
     case K_ABSEXP: le = launch_mfma_absexp(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
     default: le = launch_mfma_invdist(KS, NT, pipelined ? 3 + variant : TW, a, grid, c->stream, &c->last_kernel_name); break;
@@ -1759,7 +1769,8 @@ int run_product_mfma(kmvp_ctx* c, int kernel, int sig) {
                        (const float*)c->part.p, (const float*)c->partd.p, (const float*)c->kexp.p, (double*)c->sums.p,
                        (double*)c->kshift.p, n_pad, NEP, E, segments, sig == SIG_NORM ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
-    c->note = "exp(<x,y>) on the bf16 matrix cores with the per-target online shift, (mantissa, exponent) partial sums";
+    c->note = shifted ? "bf16 Gaussian with the per-target online shift (targets != sources)"
+                      : "exp(<x,y>) on the bf16 matrix cores with the per-target online shift, (mantissa, exponent) partial sums";
     return finish_product_shifted(c, N, n_pad, E, sig);
   }
   hipLaunchKernelGGL(mfma_reduce_kernel, dim3(blocks_for(count)), dim3(256), 0, c->stream,

@@ -326,6 +326,61 @@ def test_exp_dot_bfloat16_native_kernel_with_online_shift():
     assert seen == {"mfma_pipe_kernel", "mfma_kernel"}, seen
 
 
+def test_bfloat16_gaussian_targets_far_from_every_source():
+    """The bf16 Gaussian with targets != sources carries exp(<x,y>)'s per-target running shift (K_GAUSSIAN_SHIFTED in
+    kmvp_mfma.hpp): targets 3 ... 25 kernel lengths away from every source (kernel values down to 2^-900: the whole row far
+    under the float32 range) keep bf16 accuracy row by row -- normalised rows stay convex combinations instead of 0/0, plain
+    products come back at their own scale in float64.  Also sources sorted so that the nearest ones arrive LAST (the shift has
+    to move while sums are under way), both kernels (mfma_pipe_kernel / mfma_kernel), several segments; targets == sources keep
+    the plain kernel.  Truth: the float64 oracle on the operands the kernel multiplies (points x sqrt(log2 e) rounded to bf16)."""
+    rs = np.random.RandomState(717)
+    c = 1.2011224087864498
+    seen = set()
+    for D, N, M, E, offset in ((16, 500, 3000, 8, 3.0), (64, 300, 4096, 64, 9.0), (64, 257, 2000, 33, 25.0), (100, 100, 1500, 96, 6.0),
+                               (24, 4096, 40000, 4, 12.0)):
+        y = rs.rand(M, D) / np.sqrt(D / 3.0)
+        u = rs.randn(D)
+        x = rs.rand(N, D) / np.sqrt(D / 3.0) + offset * u / np.linalg.norm(u)
+        # nearest sources last: sort the sources by their distance to the targets' centre, descending
+        y = y[np.argsort(-((y - x.mean(axis=0)) ** 2).sum(axis=1))]
+        b = rs.randn(M, E)
+        yr, xr = bf16_round(y * c) / c, bf16_round(x * c) / c
+        for norm in (True, False):
+            algo = MI355XProduct(kernel="gaussian", dimension=D, normalize_rows=norm, precision="bfloat16")
+            try:
+                algo.prepare_data(source_points=y, target_points=x, same_points=False)
+                algo.fit()
+                algo.prepare_query(source_signal=b)
+                algo.query()
+                got = algo.get_result()
+                seen.add(algo.device_kernel)
+                note = algo.get_additional().get("dispatch_note", "")
+            finally:
+                algo.done()
+            assert "online shift" in note, note
+            rows = rs.choice(N, size=min(N, 200), replace=False)
+            want = kmvp_oracle.product(kernel="gaussian", source_points=yr, target_points=xr[rows], source_signal=b, normalize_rows=norm)
+            mass = kmvp_oracle.product(kernel="gaussian", source_points=yr, target_points=xr[rows], source_signal=np.abs(b),
+                                       normalize_rows=norm)
+            assert np.isfinite(want).all() and (mass > 0).all()
+            assert np.isfinite(got).all(), (D, offset, norm)
+            err = float((np.abs(got[rows] - want) / mass).max())
+            assert err <= TOL_BF16, (D, N, M, E, offset, norm, err)
+            if norm:
+                assert got.min() >= b.min() - 1e-2 and got.max() <= b.max() + 1e-2
+    assert seen == {"mfma_pipe_kernel", "mfma_kernel"}, seen
+    # targets == sources: the plain kernel (every row holds k = 1)
+    y = rs.rand(2000, 64) / np.sqrt(64 / 3.0)
+    algo = MI355XProduct(kernel="gaussian", dimension=64, normalize_rows=True, precision="bfloat16")
+    try:
+        algo.prepare_data(source_points=y, target_points=y, same_points=True)
+        algo.prepare_query(source_signal=rs.randn(2000, 4))
+        algo.query()
+        assert "online shift" not in algo.get_additional().get("dispatch_note", "")
+    finally:
+        algo.done()
+
+
 def test_exp_dot_bfloat16_edge_cases():
     """The bf16 exp(<x, y>) kernels at their edges: one source / one target, targets == sources, density estimation (the
     plugin passes a signal of ones), the widest instantiated shape (D = 141, E = 128: mfma_kernel), a D beyond it (refused,
