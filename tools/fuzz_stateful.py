@@ -32,6 +32,10 @@ def truth(kernel, y, x, b, norm, precision):
             want = kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=b, normalize_rows=norm)
             mass = kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=np.abs(b), normalize_rows=norm)
         return want, mass, None
+    if precision == "bfloat16":  # the operands the kernel multiplies: points x the kernel's constant, rounded to bf16
+        k = {"gaussian": C_DOT, "absolute-exponential": 1.4426950408889634, "inverse-distance": 1.0}[kernel]
+        y = bf16(y * k) / k
+        x = None if x is None else bf16(x * k) / k
     want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b, normalize_rows=norm)
     # the yardstick of a row is its mass sum_j k |b_j| (normalised rows: the weighted mean of |b|): sums of both signs cancel
     mass = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=np.abs(b), normalize_rows=norm)
@@ -93,9 +97,9 @@ def one_context(rs, steps, verbose):
                 live = np.isfinite(want).all(axis=1) & np.isfinite(mass).all(axis=1)
                 if precision != "float64":
                     live &= (np.abs(mass) < 1e37).all(axis=1) & ((np.abs(mass) > 1e-30).all(axis=1) | norm)
-                if precision == "bfloat16" and den is not None:
-                    # the bf16 kernels of the reference's three functions carry no running shift: a row whose kernel values
-                    # all lie under the float32 range is 0 (0/0 when normalised), as it is in the reference's float32
+                if precision == "bfloat16" and den is not None and kernel != "gaussian":
+                    # bf16 exp(-r) and 1/r carry no running shift (the Gaussian with targets != sources and exp<x, y> do): a row
+                    # whose kernel values all lie under the float32 range is 0 (0/0 when normalised), as in the reference's float32
                     live &= den > 1e-30
                 done += 1
                 if not live.any():
