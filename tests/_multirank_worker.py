@@ -104,6 +104,39 @@ def main():
         report.append({"kernel": "exp-dot", "precision": precision, "normalize": normalize, "rel_err": e,
                        "device_kernel": meta["device_kernel"]})
 
+    # the bf16 Gaussian with targets far from every source, sharded: the ranks' shifts differ (sources sorted by distance), the
+    # exponents are merged by all-reduce(min) exactly as for exp(<x,y>)
+    rs = np.random.RandomState(6)
+    c = 1.2011224087864498
+
+    def bf16r(a):
+        u = np.ascontiguousarray(a * c, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64) / c
+
+    y = rs.rand(3001, 32) / np.sqrt(32 / 3.0)
+    x = rs.rand(400, 32) / np.sqrt(32 / 3.0) + 14.0 / np.sqrt(32)
+    y = y[np.argsort(-((y - x.mean(axis=0)) ** 2).sum(axis=1))]
+    b = rs.randn(3001, 5)
+    for normalize in (True, False):
+        algo = MI355XProduct(kernel="gaussian", dimension=32, normalize_rows=normalize, precision="bfloat16", device=0, comm=comm)
+        try:
+            algo.prepare_data(source_points=y, target_points=x, same_points=False)
+            algo.fit()
+            algo.prepare_query(source_signal=b)
+            algo.query()
+            got = algo.get_result()
+            meta = algo.get_additional()
+        finally:
+            algo.done()
+        want = kmvp_oracle.product(kernel="gaussian", source_points=bf16r(y), target_points=bf16r(x), source_signal=b, normalize_rows=normalize)
+        mass = kmvp_oracle.product(kernel="gaussian", source_points=bf16r(y), target_points=bf16r(x), source_signal=np.abs(b),
+                                   normalize_rows=normalize)
+        e = float(np.max(np.abs(got - want) / mass))
+        assert "online shift" in meta["dispatch_note"] and meta["rccl_ranks"] == world, meta
+        assert np.isfinite(got).all() and e <= 1e-2, ("bf16 gaussian far targets", normalize, e)
+        report.append({"kernel": "gaussian", "precision": "bfloat16", "normalize": normalize, "rel_err": e,
+                       "device_kernel": meta["device_kernel"]})
+
     # sharded solvers: replicated Krylov vectors, operator summed over the ranks in every iteration
     for kernel, n, rtol in (("gaussian", 3000, 1e-6), ("inverse-distance", 1500, 1e-8)):
         y, b = kmvp_oracle.uniform_cube(n, 3)

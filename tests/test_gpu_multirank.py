@@ -47,7 +47,7 @@ def test_plugin_sharded_over_three_ranks_on_one_gpu():
     out = _spawn([os.path.join(HERE, "_multirank_worker.py")], world=3, timeout=900)
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     rep = json.loads(line)
-    assert rep["world"] == 3 and len(rep["cases"]) == 13
+    assert rep["world"] == 3 and len(rep["cases"]) == 15
     print(json.dumps(rep))
 
 
