@@ -22,6 +22,7 @@ def main():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--kernel", default="gaussian")
     p.add_argument("--shape", type=int, default=-1, help="cellmm_shape option: -1 auto, 0 = 32x32x16, 1 = 16x16x32")
+    p.add_argument("--segments", type=int, default=0, help="source segments per launch (0 = the library's choice)")
     a = p.parse_args()
     from kernel_matrix_benchmarks_amd import sharding
     from kernel_matrix_benchmarks_amd.algorithms.mi355x import MI355XProduct
@@ -37,7 +38,7 @@ def main():
             comm = sharding.Communicator(w // 2, w, lambda payload: payload, host_allreduce=lambda arr, op: None)
         algo = MI355XProduct(kernel=a.kernel, dimension=D, precision="float32", device=0, comm=comm)
         algo.prepare_data(source_points=y, target_points=y, same_points=True)
-        algo.set_query_arguments(cellmm_shape=a.shape)
+        algo.set_query_arguments(cellmm_shape=a.shape, segments=a.segments)
         algo.fit()
         algo.prepare_query(source_signal=b)
         for _ in range(5):
