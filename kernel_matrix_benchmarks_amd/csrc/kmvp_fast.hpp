@@ -68,6 +68,9 @@ struct FastArgs {
   int chunk_stages;          // stages per fp32 chunk
   int64_t j_offset;
   int64_t m_total;
+  int same_points;           // targets are the (unsharded) sources: exp(-r) then gives its own pair k = 1 exactly (s = 0 by
+                             // construction in the reference's expanded form; here s carries ~1e-7 R^2 of rounding and
+                             // sqrt turns that into 3e-4 R)
 };
 
 template <int KERNEL>
@@ -171,15 +174,15 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fast_kernel(const FastArgs a) {
 #pragma unroll
     for (int d = 0; d <= D; ++d) fast_split3f(v[d], hi[d], mid[d], lo[d]);
     fast_target_operand<D, 0>(xb[tt], h, hi, mid, lo);
-    if constexpr (KERNEL == K_INVDIST) {
-      const int64_t g = ((tile0 + tt) * FAST_TILE + r) % (a.m_total + 1);
+    if (KERNEL == K_INVDIST || (KERNEL == K_ABSEXP && a.same_points)) {
+      const int64_t g = ((tile0 + tt) * FAST_TILE + r) % (a.m_total + 1);  // (same points: the target's own index)
       jz[tt] = (g < a.m_total) ? g - a.j_offset : (int64_t)-1;
     } else {
       jz[tt] = -1;
     }
   }
   int64_t jz_lo = 0, jz_hi = -1;
-  if constexpr (KERNEL == K_INVDIST) {
+  if (KERNEL == K_INVDIST || (KERNEL == K_ABSEXP && a.same_points)) {
     const int64_t g_lo = (tile0 * FAST_TILE) % (a.m_total + 1);
     const int64_t g_hi = g_lo + (FAST_TILE * TT - 1);
     if (g_hi <= a.m_total) {
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fast_kernel(const FastArgs a) {
         }
       }
       bool check = false;
-      if constexpr (KERNEL == K_INVDIST)
+      if constexpr (KERNEL == K_INVDIST || KERNEL == K_ABSEXP)
         check = (t * FAST_TILE + FAST_TILE - 1 >= jz_lo) && (t * FAST_TILE <= jz_hi);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
@@ -259,6 +262,9 @@ __global__ void __launch_bounds__(BLOCK_THREADS) fast_kernel(const FastArgs a) {
           float k = fast_kval<KERNEL>(d[reg]);
           if constexpr (KERNEL == K_INVDIST) {
             if (check) k = (t * FAST_TILE + acc_row(reg, h) == jz[tt]) ? 0.f : k;
+          }
+          if constexpr (KERNEL == K_ABSEXP) {  // (same points) the target's own pair: r = 0
+            if (check) k = (t * FAST_TILE + acc_row(reg, h) == jz[tt]) ? 1.f : k;
           }
           if constexpr (SIG == SIG_DENSITY) {
             if (reg & 1) p1 += k; else p0 += k;

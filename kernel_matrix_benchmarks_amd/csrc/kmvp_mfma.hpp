@@ -140,45 +140,44 @@ __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
 // ---- exp(<x,y>): the per-target running shift (softmax attention without a range limit).
 // The kernel values of target i are p = 2^(s - m_i), s = <x_i, y_j> log2(e); m_i is an INTEGER that rides in the target's
 // MFMA operand (two bf16 columns: a multiple of 128 and a remainder, both exact), so a pair costs no instruction for it.
-// bf16 and fp32 share their exponent range, so m_i only has to keep the sums inside it: it is set from the row maximum of
-// the FIRST source tile a wave sees (p <= 1 there) and touched again only when a target's running denominator passes 2^64
-// -- detected for one compare per tile on the sum the denominator needs anyway, BEFORE the tile's values enter the second
-// product.  An event (wave-uniform, rare) moves m_i up by delta_i >= 0: the tile's s and the next tile's (already on their
-// way with the old operand) are lowered by delta, the denominator and the target's output rows are scaled by 2^-delta
-// (exact), the operand columns are patched.  Values more than 126 binades under a row's own maximum flush to zero.
-// Partial sums leave the kernel with their exponent (MfmaArgs::kexp = -m_i) and are merged as (mantissa, exponent) pairs.
-constexpr float MFMA_DOT_LIMIT = 1.8446744e19f;  // 2^64
+// bf16 and fp32 share their exponent range, so m_i only has to keep the values inside it: it is set from the row maximum of
+// the FIRST source tile a wave sees (p <= 1 there) and touched again only when a tile holds a value whose p would pass 2^60
+// -- seen on the tile's s itself (eight v_max3 and a compare per tile, at the top of the step: one branch per step at a
+// place where the basic block ends anyway), BEFORE any of the tile's values exists.  With every p <= 2^60 the sums of up
+// to 2^60 sources stay finite.  An event (wave-uniform, rare) moves m_i up by delta_i >= 0: the tile's s is lowered by
+// delta, the denominator and the target's output rows are scaled by 2^-delta (exact), the operand columns are patched
+// (the next tile's distances are computed after the event: with the new operand).  Values more than 126 binades under a
+// row's own maximum flush to zero.  Partial sums leave the kernel with their exponent (MfmaArgs::kexp = -m_i) and are
+// merged as (mantissa, exponent) pairs.
+constexpr float MFMA_DOT_LIMIT_LOG2 = 60.f;      // a tile with log2(p) beyond this triggers an event
 constexpr float MFMA_DOT_MAX_SHIFT = 32000.f;    // |m| < 2^15: m_hi / 128 and m_lo are bf16 integers
 
+// largest log2(p) = SGN * s of a tile's 16 values on this lane
+template <int SGN>
+__device__ __forceinline__ float mfma_tile_max(const f32x16& s) {
+  float t = fmaxf((float)SGN * s[0], (float)SGN * s[1]);
+#pragma unroll
+  for (int q = 2; q < 16; q += 2) t = fmaxf(fmaxf(t, (float)SGN * s[q]), (float)SGN * s[q + 1]);  // v_max3_f32
+  return t;
+}
+
 // one target tile of one wave.  s: the tile's 16 values per lane (target = lane & 31, both lane halves), lowered in place;
-// s_next: the next source tile's, if already computed; o: the tile's output accumulators (row acc_row(q, h) = target);
-// den: this lane's partial denominator; m: the target's shift; xlast: the target's operand of the last k-step; scratch:
-// 32 floats of LDS owned by the wave.
+// o: the tile's output accumulators (row acc_row(q, h) = target); den: this lane's partial denominator; m: the target's
+// shift; xlast: the target's operand of the last k-step; scratch: 32 floats of LDS owned by the wave.
 // SGN: log2 of a kernel value is SGN * s (+1: exp(<x,y>), s = logit - m; -1: the shifted Gaussian, s = distance^2 + m).
 template <int NT, int SGN>
-__device__ __forceinline__ void mfma_dot_event(bool first, f32x16& s, f32x16* s_next, f32x16 (&o)[NT], float& den, float& m,
-                                               bf16x8& xlast, float* scratch, int r, int h) {
-  float tmax = (float)SGN * s[0];
-#pragma unroll
-  for (int q = 1; q < 16; ++q) tmax = fmaxf(tmax, (float)SGN * s[q]);
+__device__ __forceinline__ void mfma_dot_event(bool first, f32x16& s, f32x16 (&o)[NT], float& den, float& m, bf16x8& xlast,
+                                               float* scratch, int r, int h) {
+  float tmax = mfma_tile_max<SGN>(s);
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
   float delta = ceilf(tmax);                       // the tile's largest value becomes <= 1
-  if (!first) {
-    int e = 0;
-    const float dboth = den + __shfl_xor(den, 32);
-    if (dboth > 0.f && dboth < INFINITY) (void)frexpf(dboth, &e);
-    delta = fmaxf(fmaxf(delta, (float)e), 0.f);    // ... and the running denominator <= 1; the shift only ever grows
-  }
+  if (!first) delta = fmaxf(delta, 0.f);           // afterwards the shift only ever grows
   if (!(delta == delta)) delta = 0.f;              // a NaN row stays NaN
   const float m_new = fminf(fmaxf(m + delta, -MFMA_DOT_MAX_SHIFT), MFMA_DOT_MAX_SHIFT);
   delta = m_new - m;
   m = m_new;
 #pragma unroll
   for (int q = 0; q < 16; ++q) s[q] -= (float)SGN * delta;
-  if (s_next != nullptr) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) (*s_next)[q] -= (float)SGN * delta;
-  }
   const int di = (int)delta;
   den = ldexpf(den, -di);
   // the output rows are targets too, in another layout: the deltas travel through LDS
@@ -331,8 +330,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
       for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[ks], xb[w][ks], s, 0, 0, 0);
 
       // ---- 2. kernel values on the VALU; target on the lane, 16 sources in registers
+      if constexpr (DOT) {  // (kmvp_mfma.hpp "the per-target running shift")
+        if (unset[w] || __any(mfma_tile_max<mfma_sgn<KERNEL>()>(s) > MFMA_DOT_LIMIT_LOG2)) {  // wave-uniform, rare after the first tile
+          mfma_dot_event<NT, mfma_sgn<KERNEL>()>(unset[w], s, o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
+          unset[w] = false;
+        }
+      }
       float p[16];
-      float dsum = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float k = mfma_kval<KERNEL>(s[q]);
@@ -340,21 +344,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_kernel(const MfmaArgs a) {
           if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
         }
         p[q] = k;
-        if constexpr (DOT) dsum += k;
-        else den[w] += k;
-      }
-      if constexpr (DOT) {
-        if (unset[w] || __any(!(den[w] + dsum < MFMA_DOT_LIMIT))) {  // wave-uniform, rare after the first tile
-          mfma_dot_event<NT, mfma_sgn<KERNEL>()>(unset[w], s, nullptr, o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
-          unset[w] = false;
-          dsum = 0.f;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            p[q] = mfma_kval<KERNEL>(s[q]);
-            dsum += p[q];
-          }
-        }
-        den[w] += dsum;
+        den[w] += k;
       }
 
       // ---- 3. O[i][e] += sum_j P[j][i] V[j][e]: P registers are the A operand
@@ -634,6 +624,18 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
     bool check = false;
     if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
 
+    if constexpr (DOT) {
+      // (kmvp_mfma.hpp "the per-target running shift": checked on the tile's s before any of its values exists, and before
+      // the distances of tile t + 1 are issued -- they see the patched operand)
+#pragma unroll
+      for (int w = 0; w < TW; ++w) {
+        if (unset[w] || __any(mfma_tile_max<mfma_sgn<KERNEL>()>(s_cur[w]) > MFMA_DOT_LIMIT_LOG2)) {
+          mfma_dot_event<NT, mfma_sgn<KERNEL>()>(unset[w], s_cur[w], o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
+          unset[w] = false;
+        }
+      }
+    }
+
     // Scheduling regions per source tile, each pairing MFMAs with independent VALU work of the same wave (an MFMA that
     // cannot enter the matrix pipe yet blocks the wave's following instructions, so the MFMAs are spread between the
     // transcendentals, not bunched):
@@ -647,7 +649,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
 #pragma unroll
     for (int w = 0; w < TW; ++w) {
       float p[16];
-      float dsum = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float k = mfma_kval<KERNEL>(s_cur[w][q]);
@@ -655,8 +656,7 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
           if (check) k = (j0 + acc_row(q, h) == jz[w]) ? 0.f : k;
         }
         p[q] = k;
-        if constexpr (DOT) dsum += k;
-        else if constexpr (!DEN_MFMA) den[w] += k;
+        if constexpr (!DEN_MFMA) den[w] += k;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -679,25 +679,6 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DOT) {
-        // (kmvp_mfma.hpp "the per-target running shift"; the distances of tile t + 1 are already on their way with the old
-        // operand: the event lowers them too)
-        if (unset[w] || __any(!(den[w] + dsum < MFMA_DOT_LIMIT))) {
-          mfma_dot_event<NT, mfma_sgn<KERNEL>()>(unset[w], s_cur[w], &s_next[w], o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
-          unset[w] = false;
-          dsum = 0.f;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            p[q] = mfma_kval<KERNEL>(s_cur[w][q]);
-            dsum += p[q];
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pa[w][s2][j] = (__bf16)p[8 * s2 + j];
-        }
-        den[w] += dsum;
-      }
     }
     pv(TW - 1, pa[TW - 1], vb);
     buf = buf1;

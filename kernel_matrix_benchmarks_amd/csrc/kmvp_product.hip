@@ -674,6 +674,7 @@ int run_product_fast(kmvp_ctx* c, int kernel, int sig) {
   a.chunk_stages = std::max(1, c->opt_chunk / (FAST_TILE * ST));
   a.j_offset = c->j_offset;
   a.m_total = c->m_total;
+  a.same_points = (c->same_points || c->opt_same_global) ? 1 : 0;
   const dim3 grid((unsigned)(tile_blocks * segments));
   HIP_TRY(c, mark(c, 0));
   hipError_t le;
