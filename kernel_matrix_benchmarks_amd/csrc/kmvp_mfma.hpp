@@ -142,8 +142,9 @@ __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
 // MFMA operand (two bf16 columns: a multiple of 128 and a remainder, both exact), so a pair costs no instruction for it.
 // bf16 and fp32 share their exponent range, so m_i only has to keep the values inside it: it is set from the row maximum of
 // the FIRST source tile a wave sees (p <= 1 there) and touched again only when a tile holds a value whose p would pass 2^60
-// -- seen on the tile's s itself (eight v_max3 and a compare per tile, at the top of the step: one branch per step at a
-// place where the basic block ends anyway), BEFORE any of the tile's values exists.  With every p <= 2^60 the sums of up
+// -- seen on the tile's s itself (eight v_max3 and a compare per tile; the pipelined kernel takes the verdict on tile t + 1 at
+// the end of step t, in the shadow of its last P.V MFMAs, and only tests a scalar at the top of step t + 1), BEFORE any of the
+// tile's values exists.  With every p <= 2^60 the sums of up
 // to 2^60 sources stay finite.  An event (wave-uniform, rare) moves m_i up by delta_i >= 0: the tile's s is lowered by
 // delta, the denominator and the target's output rows are scaled by 2^-delta (exact), the operand columns are patched
 // (the next tile's distances are computed after the event: with the new operand).  Values more than 126 binades under a
@@ -153,12 +154,24 @@ constexpr float MFMA_DOT_LIMIT_LOG2 = 60.f;      // a tile with log2(p) beyond t
 constexpr float MFMA_DOT_MAX_SHIFT = 32000.f;    // |m| < 2^15: m_hi / 128 and m_lo are bf16 integers
 
 // largest log2(p) = SGN * s of a tile's 16 values on this lane
+// (v_max3_f32 / v_min3_f32 spelled out: fmaxf() costs a canonicalising v_max_f32 per value on top -- 30 instead of 16
+// instructions per step on the unit that bounds these kernels.  A NaN among the values is ignored, as fmaxf would.)
 template <int SGN>
 __device__ __forceinline__ float mfma_tile_max(const f32x16& s) {
-  float t = fmaxf((float)SGN * s[0], (float)SGN * s[1]);
+  float t = s[0];
+  if constexpr (SGN > 0) {
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(s[1]), "v"(s[2]));
 #pragma unroll
-  for (int q = 2; q < 16; q += 2) t = fmaxf(fmaxf(t, (float)SGN * s[q]), (float)SGN * s[q + 1]);  // v_max3_f32
-  return t;
+    for (int q = 3; q < 15; q += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(s[q]), "v"(s[q + 1]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(s[15]), "v"(s[15]));
+    return t;
+  } else {
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(s[1]), "v"(s[2]));
+#pragma unroll
+    for (int q = 3; q < 15; q += 2) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(s[q]), "v"(s[q + 1]));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t) : "v"(t), "v"(s[15]), "v"(s[15]));
+    return -t;
+  }
 }
 
 // one target tile of one wave.  s: the tile's 16 values per lane (target = lane & 31, both lane halves), lowered in place;
@@ -462,12 +475,13 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
   float den[TW];
   __shared__ __attribute__((aligned(16))) float dscr[DOT ? WAVES_PER_BLOCK : 1][DOT ? MFMA_TILE : 1];
   float msh[TW];
-  bool unset[TW];
+  bool unset[TW], over[TW];  // over: the NEXT tile holds a value beyond the limit (wave-uniform; the first tile sets the shift anyway)
 #pragma unroll
   for (int w = 0; w < TW; ++w) {
     den[w] = 0.f;
     msh[w] = 0.f;
     unset[w] = true;
+    over[w] = false;
 #pragma unroll
     for (int q = 0; q < 16; ++q) oden[w][q] = 0.f;
 #pragma unroll
@@ -625,11 +639,12 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
     if constexpr (KERNEL == K_INVDIST) check = (j0 + MFMA_TILE - 1 >= jz_lo) && (j0 <= jz_hi);
 
     if constexpr (DOT) {
-      // (kmvp_mfma.hpp "the per-target running shift": checked on the tile's s before any of its values exists, and before
-      // the distances of tile t + 1 are issued -- they see the patched operand)
+      // (kmvp_mfma.hpp "the per-target running shift": the verdict on this tile was taken at the end of the previous step,
+      // in the shadow of its last P.V MFMAs; the event runs before any of the tile's values exists and before the
+      // distances of tile t + 1 are issued -- they see the patched operand)
 #pragma unroll
       for (int w = 0; w < TW; ++w) {
-        if (unset[w] || __any(mfma_tile_max<mfma_sgn<KERNEL>()>(s_cur[w]) > MFMA_DOT_LIMIT_LOG2)) {
+        if (unset[w] || over[w]) {
           mfma_dot_event<NT, mfma_sgn<KERNEL>()>(unset[w], s_cur[w], o[w], den[w], msh[w], xb[w][KS - 1], &dscr[wave][0], r, h);
           unset[w] = false;
         }
@@ -681,6 +696,10 @@ __global__ void __launch_bounds__(BLOCK_THREADS) mfma_pipe_kernel(const MfmaArgs
       __builtin_amdgcn_sched_barrier(0);
     }
     pv(TW - 1, pa[TW - 1], vb);
+    if constexpr (DOT) {  // the next tile's verdict, on the VALU while the matrix pipe works the last P.V MFMAs off
+#pragma unroll
+      for (int w = 0; w < TW; ++w) over[w] = __any(mfma_tile_max<mfma_sgn<KERNEL>()>(s_next[w]) > MFMA_DOT_LIMIT_LOG2);
+    }
     buf = buf1;
     __syncthreads();  // tile t + 2 has landed (vmcnt(0)), nobody reads image t any more
   };
