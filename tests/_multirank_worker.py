@@ -89,11 +89,11 @@ def main():
         if precision == "bfloat16":  # the truth on the operands the kernel multiplies (points x sqrt(log2 e), rounded to bf16)
             c = 1.2011224087864498
 
-            def bf16(a):
-                u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
-                return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64)
+            def bf16(a):  # ONE float32 product, as the packing kernel forms it, rounded to bf16, divided by c again
+                u = (np.ascontiguousarray(a, dtype=np.float32) * np.float32(c)).view(np.uint32)
+                return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64) / c
 
-            ys, xs = bf16(y * c) / c, bf16(x * c) / c
+            ys, xs = bf16(y), bf16(x)
         want = kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=b, normalize_rows=normalize)
         mass = want if normalize else kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=np.abs(b))
         scale = np.max(np.abs(mass), axis=1, keepdims=True)
@@ -110,7 +110,7 @@ def main():
     c = 1.2011224087864498
 
     def bf16r(a):
-        u = np.ascontiguousarray(a * c, dtype=np.float32).view(np.uint32)
+        u = (np.ascontiguousarray(a, dtype=np.float32) * np.float32(c)).view(np.uint32)  # ONE float32 product, as the kernel forms it
         return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64) / c
 
     y = rs.rand(3001, 32) / np.sqrt(32 / 3.0)

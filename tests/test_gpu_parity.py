@@ -268,11 +268,18 @@ def test_exp_dot_native_kernel_has_no_range_limit():
             algo.done()
 
 
-def bf16_round(a):
-    """float64 -> the nearest bfloat16 (ties to even), as float64: what the packing kernels make of float32 inputs."""
-    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+def bf16_round(a, c=None):
+    """What the bf16 packing kernels make of the plugin's float32 inputs, as float64: (float32 a) x (float32 c) -- ONE float32
+    product, as the kernel forms it -- rounded to the nearest bfloat16 (ties to even), then divided by c again.  (Multiplying in
+    float64 instead lands on the other side of a bf16 rounding boundary for about one operand in a million, and a logit of
+    ~1000 then moves by half a unit: a one-row artefact of the emulation that looked like a kernel defect.)"""
+    v = np.ascontiguousarray(a, dtype=np.float32)
+    if c is not None:
+        v = v * np.float32(c)
+    u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32)
     u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
-    return u.view(np.float32).astype(np.float64)
+    r = u.view(np.float32).astype(np.float64)
+    return r if c is None else r / c
 
 
 def test_exp_dot_bfloat16_native_kernel_with_online_shift():
@@ -308,7 +315,7 @@ def test_exp_dot_bfloat16_native_kernel_with_online_shift():
             rows = rs.choice(N, size=min(N, 200), replace=False)
             # the truth on the operands the kernel multiplies: (x c) and (y c) rounded to bf16, c = sqrt(log2 e)
             c = 1.2011224087864498
-            xr, yr = bf16_round(x[rows] * c) / c, bf16_round(y * c) / c
+            xr, yr = bf16_round(x[rows], c), bf16_round(y, c)
             with np.errstate(over="ignore", invalid="ignore"):
                 want = kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr, source_signal=b, normalize_rows=norm)
                 mass = want if norm else kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr, source_signal=np.abs(b))
@@ -344,7 +351,7 @@ def test_bfloat16_gaussian_targets_far_from_every_source():
         # nearest sources last: sort the sources by their distance to the targets' centre, descending
         y = y[np.argsort(-((y - x.mean(axis=0)) ** 2).sum(axis=1))]
         b = rs.randn(M, E)
-        yr, xr = bf16_round(y * c) / c, bf16_round(x * c) / c
+        yr, xr = bf16_round(y, c), bf16_round(x, c)
         for norm in (True, False):
             algo = MI355XProduct(kernel="gaussian", dimension=D, normalize_rows=norm, precision="bfloat16")
             try:
@@ -400,7 +407,7 @@ def test_exp_dot_bfloat16_edge_cases():
             algo.done()
 
     def truth(y, x, b, norm):
-        yr, xr = bf16_round(y * c) / c, bf16_round(x * c) / c
+        yr, xr = bf16_round(y, c), bf16_round(x, c)
         want = kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr, source_signal=b, normalize_rows=norm)
         mass = want if norm else kmvp_oracle.exp_dot_product(source_points=yr, target_points=xr,
                                                               source_signal=None if b is None else np.abs(b))

@@ -179,11 +179,11 @@ def check_exp_dot(c, got, y, x, b, rows):
     if c["precision"] == "bfloat16":  # the truth on the operands the kernel multiplies: points x sqrt(log2 e), rounded to bf16
         k = 1.2011224087864498
 
-        def bf16(a):
-            u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
-            return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64)
+        def bf16(a, c):  # ONE float32 product, as the packing kernel forms it, then round-to-nearest-even to bf16
+            u = (np.ascontiguousarray(a, dtype=np.float32) * np.float32(c)).view(np.uint32)
+            return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64) / c
 
-        y, xt = bf16(y * k) / k, bf16(xt * k) / k
+        y, xt = bf16(y, k), bf16(xt, k)
     with np.errstate(over="ignore", invalid="ignore"):
         want = kmvp_oracle.exp_dot_product(source_points=y, target_points=xt, source_signal=b, normalize_rows=c["norm"])
         # the yardstick of a row is its mass: sum_j k |b_j|, or the weighted mean of |b| for a softmax row (means of both signs cancel)

@@ -18,24 +18,25 @@ KERNELS = ("gaussian", "absolute-exponential", "inverse-distance", "exp-dot")
 C_DOT = 1.2011224087864498
 
 
-def bf16(a):
-    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
-    return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64)
+def bf16(a, c):
+    """(float32 a) x (float32 c) as ONE float32 product -- what the packing kernels form -- rounded to bf16, divided by c again"""
+    u = (np.ascontiguousarray(a, dtype=np.float32) * np.float32(c)).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32).view(np.float32).astype(np.float64) / c
 
 
 def truth(kernel, y, x, b, norm, precision):
     if kernel == "exp-dot":
         ys, xs = y, (y if x is None else x)
         if precision == "bfloat16":
-            ys, xs = bf16(ys * C_DOT) / C_DOT, bf16(xs * C_DOT) / C_DOT
+            ys, xs = bf16(ys, C_DOT), bf16(xs, C_DOT)
         with np.errstate(over="ignore", invalid="ignore"):
             want = kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=b, normalize_rows=norm)
             mass = kmvp_oracle.exp_dot_product(source_points=ys, target_points=xs, source_signal=np.abs(b), normalize_rows=norm)
         return want, mass, None
     if precision == "bfloat16":  # the operands the kernel multiplies: points x the kernel's constant, rounded to bf16
         k = {"gaussian": C_DOT, "absolute-exponential": 1.4426950408889634, "inverse-distance": 1.0}[kernel]
-        y = bf16(y * k) / k
-        x = None if x is None else bf16(x * k) / k
+        y = bf16(y, k)
+        x = None if x is None else bf16(x, k)
     want = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=b, normalize_rows=norm)
     # the yardstick of a row is its mass sum_j k |b_j| (normalised rows: the weighted mean of |b|): sums of both signs cancel
     mass = kmvp_oracle.product(kernel=kernel, source_points=y, target_points=x, source_signal=np.abs(b), normalize_rows=norm)
