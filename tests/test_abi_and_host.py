@@ -438,3 +438,16 @@ def test_bench_roofline_tables_and_committed_profiles():
         text = open(md).read()
         assert kname in text or (kname == "cellmm_kernel" and "cellmm16_kernel" in text), md
     assert bench.traffic_from_profile("no_such_kernel", "gaussian_1e6_f32") == (None, None)
+
+
+def test_tools_and_entry_points_parse():
+    """Every script under tools/ (probes, sweeps, profile summarisers), bench.py and __graft_entry__.py is valid Python and has
+    a docstring saying what it measures: they are run by hand on a GPU box, nothing else keeps them alive."""
+    import ast
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    assert len(paths) > 20
+    for p in paths:
+        tree = ast.parse(open(p).read(), filename=p)
+        assert ast.get_docstring(tree), f"{os.path.relpath(p, ROOT)} has no docstring"

@@ -1,3 +1,4 @@
+"""Config 3's kernel on random against all-zero points / signals: how much of its time is the chip's power limit (the same instruction stream on zero operands runs at the full clock)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

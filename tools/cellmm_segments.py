@@ -1,3 +1,4 @@
+"""cellmm_kernel at N = M = 1e6 against the number of source segments (option "segments"): kernel time per setting."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

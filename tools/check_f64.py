@@ -1,3 +1,4 @@
+"""float64 products (Gaussian, exp(-r)) on clouds of growing extent against the numpy oracle, and the float64 cell form at 1e5 points."""
 import os, sys, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))

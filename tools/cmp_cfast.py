@@ -1,3 +1,4 @@
+"""cfast_kernel (1, 2, 4 target tiles per wave) against the difference form: time and agreement.  usage: python tools/cmp_cfast.py n [kernel ...]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, '/root/repo' if os.path.isdir('/root/repo/kernel_matrix_benchmarks_amd') else os.environ.get('GRAFT_REPO_ROOT','.'))

@@ -1,3 +1,4 @@
+"""Debugging aid: bf16 exp(-r) attention at small shapes under every mfma_variant, twice each (run-to-run equality, error against the oracle)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

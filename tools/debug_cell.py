@@ -1,3 +1,4 @@
+"""Debugging aid for the cell kernels: small clouds through cell_kernel / cellmm_kernel against a direct numpy sum."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,3 +1,4 @@
+"""Error of config 2's forms (cells on the matrix cores / on the VALU / expanded) on 4096 oracle rows, next to what rounding the inputs to float32 alone costs."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
 import numpy as np, c_oracle, kmvp_oracle

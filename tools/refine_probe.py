@@ -1,3 +1,4 @@
+"""Config 5 by mixed-precision refinement at several inner tolerances: seconds, inner iterations, refinement steps, float64 residual."""
 import os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
 import numpy as np, c_oracle, kmvp_oracle

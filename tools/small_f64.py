@@ -1,3 +1,4 @@
+"""float64 Gaussian products at the reference's dataset sizes (1000 ... 10000 sphere points) against the segment count: time and error."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
